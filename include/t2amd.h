@@ -1,0 +1,153 @@
+/* t2amd.h — C ABI of the MI355X-native Tacotron2 (BERT_Tacotron2) hot path.
+ *
+ * The reference (PhucNguyenAH/tacotron2_subword) is pure Python on PyTorch and has no FFI;
+ * its operator boundary for this path is the Python module API (model.py / attention.py).
+ * Each entry point below names the reference interface it replaces (file:line, relative to
+ * the reference checkout).  A ctypes binding a maintainer would add is shown in
+ * INTEGRATION.md; tacotron2_subword_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; fp32, row-major;
+ *   - the caller owns every buffer (workspace sizes come from the *_ws_bytes queries);
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*); no call allocates device
+ *     memory; no call synchronises except t2_decoder_infer (documented there);
+ *   - return value 0 = OK, < 0 = error; t2_last_error() gives a thread-local message;
+ *   - activations are channels-last: [B, T, C].  Conversion to the reference's [B, C, T]
+ *     happens in t2_finalize_outputs.
+ */
+#ifndef T2AMD_H
+#define T2AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T2_ATTN_SMA 0 /* StepwiseMonotonicAttention, attention.py:291-398 (hparams default) */
+#define T2_ATTN_LSA 1 /* LocationSensitiveAttention, attention.py:25-85 */
+
+/* RNG sites: a dropout keep-bit / noise sample is a pure function of (seed, site, index). */
+enum {
+    T2_SITE_PRENET1 = 1, T2_SITE_PRENET2 = 2, T2_SITE_PRENET1_SUB = 3, T2_SITE_PRENET2_SUB = 4,
+    T2_SITE_ATT_H = 5, T2_SITE_ATT_C = 6, T2_SITE_ATT_H_SUB = 7, T2_SITE_ATT_C_SUB = 8,
+    T2_SITE_DEC_H = 9, T2_SITE_DEC_C = 10, T2_SITE_NOISE = 11, T2_SITE_NOISE_SUB = 12,
+    T2_SITE_ENC0 = 16,      /* +layer (0..2) */
+    T2_SITE_ENCSUB0 = 20,   /* +layer (0..2) */
+    T2_SITE_POSTNET0 = 24   /* +layer (0..4) */
+};
+
+const char* t2_last_error(void);
+int t2_version(void);
+
+/* Model dimensions (hparams.py:55-95). */
+typedef struct t2_dims {
+    int n_mel;          /* n_mel_channels * n_frames_per_step (80) */
+    int prenet_dim;     /* 256 */
+    int enc_dim;        /* encoder_embedding_dim E (512) */
+    int att_rnn_dim;    /* 1024 */
+    int dec_rnn_dim;    /* 1024 */
+    int att_dim;        /* attention_dim A (128) */
+    int loc_filters;    /* 32 */
+    int loc_kernel;     /* 31 */
+    int attention_kind; /* T2_ATTN_* */
+    float p_att_dropout, p_dec_dropout, p_prenet_dropout; /* 0.1, 0.1, 0.5 */
+} t2_dims;
+
+/* Parameters of Decoder (model.py:128-207), reference state_dict names in comments. */
+typedef struct t2_attention_weights {
+    const float* wq;        /* query_layer.linear_layer.weight        [A, att_rnn] */
+    const float* wm;        /* memory_layer.linear_layer.weight       [A, E] */
+    const float* v;         /* v.weight | v.linear_layer.weight       [1, A] */
+    const float* loc_conv;  /* location_layer.location_conv.conv.weight   [F,2,Kc] (LSA) */
+    const float* loc_dense; /* location_layer.location_dense.linear_layer.weight [A,F] (LSA) */
+} t2_attention_weights;
+typedef struct t2_lstm_weights { const float *w_ih, *w_hh, *b_ih, *b_hh; } t2_lstm_weights;
+typedef struct t2_decoder_weights {
+    const float *prenet_w1, *prenet_w2;          /* decoder.prenet.layers.{0,1}.linear_layer.weight */
+    const float *prenet_sub_w1, *prenet_sub_w2;  /* decoder.prenet_bert.layers.{0,1}... */
+    t2_lstm_weights att, att_sub;                /* decoder.attention_rnn, decoder.attention_rnn_bert */
+    t2_attention_weights attn, attn_sub;         /* decoder.attention_layer, decoder.attention_layer_bert */
+    t2_lstm_weights dec;                         /* decoder.decoder_rnn */
+    const float *proj_w, *proj_b;                /* decoder.linear_projection.linear_layer.{weight,bias} */
+    const float *gate_w, *gate_b;                /* decoder.gate_layer.linear_layer.{weight,bias} */
+} t2_decoder_weights;
+
+/* Saved-activation workspace of one decoder pass.  Offsets are in floats from `ws`. */
+typedef struct t2_decoder_layout {
+    size_t total_floats;
+    size_t x, p1, p2, p1s, p2s;      /* [B,T,n_mel], prenet activations [B,T,prenet] */
+    size_t pm, pms;                   /* processed memory [B,Tin,A], [B,Tsub,A] */
+    size_t prea, preas;               /* attention-LSTM input pre-activations [B,T,4*Ha] */
+    size_t ga, gas;                   /* activated gates i,f,g,o [B,T,4*Ha] */
+    size_t cna, cnas, ca, cas;        /* cell before / after dropout [B,T,Ha] */
+    size_t din;                       /* [B,T, 2*Ha+2*E] = att_h | ctx | att_h_sub | ctx_sub */
+    size_t psel, psels;               /* SMA p_t [B,T,Tin], [B,T,Tsub] */
+    size_t wcum, wcums;               /* LSA cumulative weights per step [B,T,Tin], [B,T,Tsub] */
+    size_t pred, gd, cnd, cd;         /* decoder LSTM: pre-activations, gates [B,T,4*Hd], cells [B,T,Hd] */
+    size_t dout;                      /* [B,T, Hd+2*E] = dec_h | ctx | ctx_sub */
+    size_t qpart;                     /* per-step scratch [2][Ha/8][B][A] */
+    size_t gemm_ws; size_t gemm_ws_floats;
+} t2_decoder_layout;
+
+int t2_decoder_layout_query(const t2_dims* dims, int B, int T, int Tin, int Tsub, t2_decoder_layout* out);
+
+/* Teacher-forced decoder pass — replaces Decoder.forward (model.py:392-428) incl. both Prenets
+ * (:13-24), initialize_decoder_states (:223-270) and T calls of Decoder.decode (:322-390). */
+typedef struct t2_decoder_fwd_args {
+    int B, T, Tin, Tsub;
+    const float* memory;      /* [B,Tin,E]   linear_converter output */
+    const float* memory_sub;  /* [B,Tsub,E] */
+    const int32_t* mem_lengths;  /* [B] or NULL (no mask, as in Decoder.inference) */
+    const int32_t* sub_lengths;
+    const float* mels;        /* [B,n_mel,T] teacher frames (reference layout) */
+    float* mel_out;           /* [B,T,n_mel] */
+    float* gate_out;          /* [B,T] */
+    float* align;             /* [B,T,Tin] */
+    float* align_sub;         /* [B,T,Tsub] */
+    float* ws;                /* t2_decoder_layout.total_floats floats */
+    int training;             /* LSTM-state dropout + SMA noise on (model.train()) */
+    int prenet_dropout;       /* 1 = reference behaviour (always on, model.py:23); 0 = off for deterministic parity */
+    uint64_t seed;
+} t2_decoder_fwd_args;
+int t2_decoder_forward(const t2_dims* dims, const t2_decoder_weights* w, const t2_decoder_fwd_args* a, void* stream);
+
+/* Autoregressive decode — replaces Decoder.inference (model.py:430-492) for any B.
+ * Per-item stop rule: stop_index[b] = first t with sigmoid(gate) > threshold.
+ * Runs until every item has stopped or max_steps; the host polls a device counter every
+ * `poll_every` steps (the only synchronisation).  Returns the number of steps run in
+ * *steps_run_host; frames after an item's stop are computed-but-meaningless. */
+typedef struct t2_decoder_infer_args {
+    int B, Tin, Tsub, max_steps, poll_every;
+    float gate_threshold;
+    const float* memory; const float* memory_sub;
+    const int32_t* mem_lengths; const int32_t* sub_lengths;   /* NULL as in the reference */
+    float* mel_out;     /* [B,max_steps,n_mel] */
+    float* gate_out;    /* [B,max_steps] */
+    float* align;       /* [B,max_steps,Tin] */
+    float* align_sub;   /* [B,max_steps,Tsub] */
+    int32_t* stop_index;/* [B] device, -1 = never crossed */
+    int32_t* done_count;/* [1] device scratch */
+    float* ws;          /* layout for T = max_steps */
+    int prenet_dropout; uint64_t seed;
+    int* steps_run_host;
+} t2_decoder_infer_args;
+int t2_decoder_infer(const t2_dims* dims, const t2_decoder_weights* w, const t2_decoder_infer_args* a, void* stream);
+
+/* out[b,c,t] = t < lengths[b] ? in[b,t,c] : fill — the layout change + masked_fill of
+ * BERT_Tacotron2.parse_output (model.py:531-541).  lengths may be NULL. */
+int t2_finalize_bct(const float* in_btc, float* out_bct, int B, int T, int C, const int32_t* lengths, float fill, void* stream);
+int t2_mask_bt(float* x, int B, int T, const int32_t* lengths, float fill, void* stream);
+
+/* Unit-testable pieces. */
+int t2_gemm(const float* A, const float* B, float* C, int M, int N, int K,
+            long sam, long sak, long sbn, long sbk, long ldc,
+            const float* bias, int act, float alpha, float beta,
+            float* ws, size_t ws_bytes, int splitk, void* stream);
+int t2_rng_keep_mask(uint64_t seed, uint32_t site, uint32_t n, float p, uint8_t* out, void* stream);
+int t2_rng_normal(uint64_t seed, uint32_t site, uint32_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T2AMD_H */

@@ -1,0 +1,153 @@
+"""ctypes binding of the C-ABI HIP library (include/t2amd.h).
+
+The product path has no CPU fallback: if ``libt2amd.so`` is missing or a call fails, this
+module raises.  Build the library with ``python -c "import __graft_entry__ as g; g.build()"``
+(or ``tacotron2_subword_amd.build.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libt2amd.so")
+
+ATTN_SMA, ATTN_LSA = 0, 1
+
+SITE = dict(PRENET1=1, PRENET2=2, PRENET1_SUB=3, PRENET2_SUB=4, ATT_H=5, ATT_C=6, ATT_H_SUB=7, ATT_C_SUB=8,
+            DEC_H=9, DEC_C=10, NOISE=11, NOISE_SUB=12, ENC0=16, ENCSUB0=20, POSTNET0=24)
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+
+class Dims(C.Structure):
+    _fields_ = [("n_mel", C.c_int), ("prenet_dim", C.c_int), ("enc_dim", C.c_int), ("att_rnn_dim", C.c_int),
+                ("dec_rnn_dim", C.c_int), ("att_dim", C.c_int), ("loc_filters", C.c_int), ("loc_kernel", C.c_int),
+                ("attention_kind", C.c_int), ("p_att_dropout", C.c_float), ("p_dec_dropout", C.c_float),
+                ("p_prenet_dropout", C.c_float)]
+
+
+class AttentionWeights(C.Structure):
+    _fields_ = [("wq", C.c_void_p), ("wm", C.c_void_p), ("v", C.c_void_p), ("loc_conv", C.c_void_p), ("loc_dense", C.c_void_p)]
+
+
+class LstmWeights(C.Structure):
+    _fields_ = [("w_ih", C.c_void_p), ("w_hh", C.c_void_p), ("b_ih", C.c_void_p), ("b_hh", C.c_void_p)]
+
+
+class DecoderWeights(C.Structure):
+    _fields_ = [("prenet_w1", C.c_void_p), ("prenet_w2", C.c_void_p), ("prenet_sub_w1", C.c_void_p), ("prenet_sub_w2", C.c_void_p),
+                ("att", LstmWeights), ("att_sub", LstmWeights), ("attn", AttentionWeights), ("attn_sub", AttentionWeights),
+                ("dec", LstmWeights), ("proj_w", C.c_void_p), ("proj_b", C.c_void_p), ("gate_w", C.c_void_p), ("gate_b", C.c_void_p)]
+
+
+_LAYOUT_FIELDS = ["total_floats", "x", "p1", "p2", "p1s", "p2s", "pm", "pms", "prea", "preas", "ga", "gas",
+                  "cna", "cnas", "ca", "cas", "din", "psel", "psels", "wcum", "wcums", "pred", "gd", "cnd", "cd",
+                  "dout", "qpart", "gemm_ws", "gemm_ws_floats"]
+
+
+class DecoderLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in _LAYOUT_FIELDS]
+
+
+class DecoderFwdArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("Tin", C.c_int), ("Tsub", C.c_int),
+                ("memory", C.c_void_p), ("memory_sub", C.c_void_p), ("mem_lengths", C.c_void_p), ("sub_lengths", C.c_void_p),
+                ("mels", C.c_void_p), ("mel_out", C.c_void_p), ("gate_out", C.c_void_p), ("align", C.c_void_p),
+                ("align_sub", C.c_void_p), ("ws", C.c_void_p), ("training", C.c_int), ("prenet_dropout", C.c_int),
+                ("seed", C.c_uint64)]
+
+
+class DecoderInferArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("Tin", C.c_int), ("Tsub", C.c_int), ("max_steps", C.c_int), ("poll_every", C.c_int),
+                ("gate_threshold", C.c_float),
+                ("memory", C.c_void_p), ("memory_sub", C.c_void_p), ("mem_lengths", C.c_void_p), ("sub_lengths", C.c_void_p),
+                ("mel_out", C.c_void_p), ("gate_out", C.c_void_p), ("align", C.c_void_p), ("align_sub", C.c_void_p),
+                ("stop_index", C.c_void_p), ("done_count", C.c_void_p), ("ws", C.c_void_p),
+                ("prenet_dropout", C.c_int), ("seed", C.c_uint64), ("steps_run_host", C.POINTER(C.c_int))]
+
+
+# every symbol include/t2amd.h declares (tests/test_abi.py checks the library exports them all)
+EXPORTS = ["t2_last_error", "t2_version", "t2_decoder_layout_query", "t2_decoder_forward", "t2_decoder_infer",
+           "t2_finalize_bct", "t2_mask_bt", "t2_gemm", "t2_rng_keep_mask", "t2_rng_normal"]
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: the HIP extension must be built (see __graft_entry__.build); "
+                               "there is no CPU fallback for the product path")
+        L = C.CDLL(LIB_PATH)
+        L.t2_last_error.restype = C.c_char_p
+        L.t2_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long,
+                              C.c_long, C.c_long, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_size_t,
+                              C.c_int, C.c_void_p]
+        L.t2_rng_keep_mask.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p]
+        L.t2_rng_normal.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.t2_decoder_layout_query.argtypes = [C.POINTER(Dims), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(DecoderLayout)]
+        L.t2_decoder_forward.argtypes = [C.POINTER(Dims), C.POINTER(DecoderWeights), C.POINTER(DecoderFwdArgs), C.c_void_p]
+        L.t2_decoder_infer.argtypes = [C.POINTER(Dims), C.POINTER(DecoderWeights), C.POINTER(DecoderInferArgs), C.c_void_p]
+        L.t2_finalize_bct.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p]
+        L.t2_mask_bt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError(f"t2amd call failed ({rc}): {lib().t2_last_error().decode()}")
+
+
+def ptr(t: torch.Tensor | None) -> int | None:
+    """Device pointer of a contiguous CUDA(HIP) tensor; None -> NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("t2amd: tensors must live on the GPU (no CPU fallback in the product path)")
+    if not t.is_contiguous():
+        raise RuntimeError("t2amd: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dims_from_hparams(hp) -> Dims:
+    g = (lambda k: hp[k]) if isinstance(hp, dict) else (lambda k: getattr(hp, k))
+    kind = ATTN_SMA if g("attention") == "StepwiseMonotonicAttention" else ATTN_LSA
+    return Dims(int(g("n_mel_channels")) * int(g("n_frames_per_step")), int(g("prenet_dim")), int(g("encoder_embedding_dim")),
+                int(g("attention_rnn_dim")), int(g("decoder_rnn_dim")), int(g("attention_dim")),
+                int(g("attention_location_n_filters")), int(g("attention_location_kernel_size")), kind,
+                float(g("p_attention_dropout")), float(g("p_decoder_dropout")), 0.5)
+
+
+def decoder_weights(P: dict, kind: int, prefix: str = "decoder.") -> DecoderWeights:
+    """Pack device pointers of a (reference-keyed) state dict; the tensors must outlive the call."""
+    p = lambda k: ptr(P[prefix + k])
+    lstm = lambda n: LstmWeights(p(n + ".weight_ih"), p(n + ".weight_hh"), p(n + ".bias_ih"), p(n + ".bias_hh"))
+
+    def attn(n):
+        if kind == ATTN_SMA:
+            return AttentionWeights(p(n + ".query_layer.linear_layer.weight"), p(n + ".memory_layer.linear_layer.weight"),
+                                    p(n + ".v.weight"), None, None)
+        return AttentionWeights(p(n + ".query_layer.linear_layer.weight"), p(n + ".memory_layer.linear_layer.weight"),
+                                p(n + ".v.linear_layer.weight"), p(n + ".location_layer.location_conv.conv.weight"),
+                                p(n + ".location_layer.location_dense.linear_layer.weight"))
+    return DecoderWeights(p("prenet.layers.0.linear_layer.weight"), p("prenet.layers.1.linear_layer.weight"),
+                          p("prenet_bert.layers.0.linear_layer.weight"), p("prenet_bert.layers.1.linear_layer.weight"),
+                          lstm("attention_rnn"), lstm("attention_rnn_bert"), attn("attention_layer"), attn("attention_layer_bert"),
+                          lstm("decoder_rnn"), p("linear_projection.linear_layer.weight"), p("linear_projection.linear_layer.bias"),
+                          p("gate_layer.linear_layer.weight"), p("gate_layer.linear_layer.bias"))
+
+
+def decoder_layout(dims: Dims, B: int, T: int, Tin: int, Tsub: int) -> DecoderLayout:
+    L = DecoderLayout()
+    check(lib().t2_decoder_layout_query(C.byref(dims), B, T, Tin, Tsub, C.byref(L)))
+    return L

@@ -1,0 +1,234 @@
+// One attention step for both decoder streams (phone / sub-word) in one launch:
+// one workgroup per (batch item, stream).
+//
+//   kind 0  StepwiseMonotonicAttention.forward   (attention.py:374-398)
+//           e_j = v . tanh(q + pm_j) ; mask -> -inf ; (+ noise*std in training) ; p = sigmoid(e)
+//           a_t[j] = a_{t-1}[j] p_j + a_{t-1}[j-1] (1 - p_{j-1})   ; ctx = a_t . memory
+//   kind 1  LocationSensitiveAttention.forward   (attention.py:64-85, LocationLayer :7-23)
+//           e_j = v . tanh(q + dense(conv([w_prev; w_cum]))_j + pm_j) ; mask ; softmax ; ctx = w . memory
+//
+// The processed-memory rows (A floats) are read 16 B per lane by groups of 16 lanes per
+// position j and reduced with wave shuffles; the encoder memory rows (E floats) are read
+// 16 B per lane, fully coalesced, once per step.  Positions whose weight is exactly 0 are
+// skipped in the context sum (SMA alignments are sparse early on; 0*x contributes nothing).
+#include "kernels.h"
+
+namespace t2 {
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+    // red: >= 4 floats of LDS; result broadcast to all threads
+    v = is_max ? wave_max(v) : wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+    return r;
+}
+
+__global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) {
+    const AttnStream& st = d.st[blockIdx.y];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int Tin = st.Tin, A = d.A, E = d.E, F = d.F, Kc = d.Kc;
+    const int Tp = (Tin + 3) & ~3;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* q = smem;                 // [A]
+    float* vs = q + A;               // [A]
+    float* e = vs + A;               // [Tp]
+    float* ap = e + Tp;              // [Tp]
+    float* an = ap + Tp;             // [Tp]
+    float* red = an + Tp;            // [NT]
+    float* cred = red + NT;          // [nh*E]
+    const int nd = E / 4, nh = NT / nd;
+    float* lsa = cred + nh * E;      // LSA only: convw[F*2*Kc] dense[A*(F+1)] loc[Tin*(F+1)] wpad[2][Tin+Kc-1]
+
+    // ---- query: direct, or ordered sum of the partials emitted by lstm_step_fwd
+    if (st.qpart) {
+        const int nq = NT / A;       // A <= NT checked on the host
+        const int h = tid / A, a = tid % A;
+        if (h < nq) {
+            float sum = 0.f;
+            const float* p = st.qpart + (long)b * A + a;
+            const long ps = (long)d.B * A;
+            for (int i = h; i < st.nparts; i += nq) sum += p[(long)i * ps];
+            red[h * A + a] = sum;
+        }
+        __syncthreads();
+        if (tid < A) {
+            float sum = 0.f;
+            for (int h2 = 0; h2 < nq; ++h2) sum += red[h2 * A + tid];
+            q[tid] = sum;
+        }
+    } else {
+        for (int a = tid; a < A; a += NT) q[a] = st.query[(long)b * st.ldq + a];
+    }
+    for (int a = tid; a < A; a += NT) vs[a] = st.v[a];
+
+    // previous alignment / weights
+    for (int j = tid; j < Tin; j += NT)
+        ap[j] = st.a_prev ? st.a_prev[(long)b * st.lda_prev + j] : ((d.kind == 0 && j == 0) ? 1.f : 0.f);
+
+    float* loc = nullptr; float* dense = nullptr;
+    if (d.kind == 1) {
+        float* convw = lsa;
+        dense = convw + F * 2 * Kc;
+        loc = dense + A * (F + 1);
+        float* wpad = loc + Tin * (F + 1);
+        const int pad = (Kc - 1) / 2, Tw = Tin + Kc - 1;
+        for (int i = tid; i < F * 2 * Kc; i += NT) convw[i] = st.loc_conv[i];
+        for (int i = tid; i < A * F; i += NT) dense[(i / F) * (F + 1) + (i % F)] = st.loc_dense[i];
+        for (int i = tid; i < 2 * Tw; i += NT) {
+            const int c = i / Tw, j = i % Tw - pad;
+            float v = 0.f;
+            if (j >= 0 && j < Tin) v = c == 0 ? (st.a_prev ? st.a_prev[(long)b * st.lda_prev + j] : 0.f)
+                                              : (st.wcum_prev ? st.wcum_prev[(long)b * st.ldwcum_prev + j] : 0.f);
+            wpad[i] = v;
+        }
+        __syncthreads();
+        // location conv: loc[j][f] = sum_c sum_k convw[f][c][k] * wcat[c][j + k - pad]
+        for (int i = tid; i < Tin * F; i += NT) {
+            const int j = i / F, f = i % F;
+            float sum = 0.f;
+            for (int c = 0; c < 2; ++c) {
+                const float* w = convw + (f * 2 + c) * Kc;
+                const float* x = wpad + c * Tw + j;
+                for (int k = 0; k < Kc; ++k) sum += w[k] * x[k];
+            }
+            loc[j * (F + 1) + f] = sum;
+        }
+    }
+    __syncthreads();
+
+    // ---- energies: 16 lanes per position j
+    {
+        const int gid = tid >> 4, sub = tid & 15;
+        for (int j = gid; j < Tp; j += NT / 16) {       // Tp keeps whole 16-lane groups converged for the shuffles
+            float sum = 0.f;
+            if (j < Tin) {
+                const float* pmr = st.pm + ((long)b * Tin + j) * A;
+                for (int a = sub * 4; a < A; a += 64) {
+                    f32x4 pv = *reinterpret_cast<const f32x4*>(pmr + a);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float u = q[a + c] + pv[c];
+                        if (d.kind == 1) {
+                            float pa = 0.f;
+                            const float* dr = dense + (a + c) * (F + 1);
+                            const float* lr = loc + j * (F + 1);
+                            for (int f = 0; f < F; ++f) pa += dr[f] * lr[f];
+                            u += pa;
+                        }
+                        sum += vs[a + c] * tanhf(u);
+                    }
+                }
+            }
+            sum += __shfl_xor(sum, 8, 64); sum += __shfl_xor(sum, 4, 64);
+            sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 1, 64);
+            if (sub == 0 && j < Tin) e[j] = sum;
+        }
+    }
+    __syncthreads();
+
+    const int len = st.lengths ? st.lengths[b] : Tin;
+    if (d.kind == 0) {
+        const RngKey key = rng_key(d.seed, st.site_noise);
+        for (int j = tid; j < Tin; j += NT) {
+            float ev = e[j];
+            if (j >= len) ev = d.mask_value;
+            if (d.noise_std > 0.f) ev += d.noise_std * rng_normal(key, st.idx_base + (uint32_t)b * st.idx_bstride + (uint32_t)j);
+            const float p = sigmoidf_(ev);
+            e[j] = p;
+            if (st.p_out) st.p_out[(long)b * st.ldp_out + j] = p;
+        }
+        __syncthreads();
+        for (int j = tid; j < Tin; j += NT) {
+            float a = ap[j] * e[j];
+            if (j > 0) a += ap[j - 1] * (1.0f - e[j - 1]);
+            an[j] = a;
+            st.a_out[(long)b * st.lda_out + j] = a;
+        }
+    } else {
+        float mx = -INFINITY;
+        for (int j = tid; j < Tin; j += NT) {
+            float ev = e[j];
+            if (j >= len) ev = d.mask_value;
+            e[j] = ev;
+            mx = fmaxf(mx, ev);
+        }
+        mx = block_reduce(mx, red, true);
+        float sum = 0.f;
+        for (int j = tid; j < Tin; j += NT) { const float x = expf(e[j] - mx); e[j] = x; sum += x; }
+        sum = block_reduce(sum, red, false);
+        const float inv = 1.0f / sum;
+        for (int j = tid; j < Tin; j += NT) {
+            const float w = e[j] * inv;
+            an[j] = w;
+            st.a_out[(long)b * st.lda_out + j] = w;
+            if (st.wcum_out)
+                st.wcum_out[(long)b * st.ldwcum_out + j] = (st.wcum_prev ? st.wcum_prev[(long)b * st.ldwcum_prev + j] : 0.f) + w;
+        }
+    }
+    __syncthreads();
+
+    // ---- context: nh groups of nd lanes, each lane 4 channels; group h takes j = h, h+nh, ...
+    {
+        const int h = tid / nd, dd = (tid % nd) * 4;
+        if (h < nh) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* mp = st.memory + (long)b * Tin * E + dd;
+            for (int j = h; j < Tin; j += nh) {
+                const float a = an[j];
+                if (a != 0.f) {
+                    const f32x4 mv = *reinterpret_cast<const f32x4*>(mp + (long)j * E);
+                    acc += a * mv;
+                }
+            }
+            *reinterpret_cast<f32x4*>(cred + h * E + dd) = acc;
+        }
+        __syncthreads();
+        for (int c = tid; c < E; c += NT) {
+            float sum = 0.f;
+            for (int h2 = 0; h2 < nh; ++h2) sum += cred[h2 * E + c];
+            st.ctx1[(long)b * st.ldctx1 + c] = sum;
+            if (st.ctx2) st.ctx2[(long)b * st.ldctx2 + c] = sum;
+        }
+    }
+}
+
+}  // namespace
+
+size_t attention_fwd_smem(const AttnStepDesc& d) {
+    int Tmax = 0;
+    for (int i = 0; i < d.nstreams; ++i) Tmax = d.st[i].Tin > Tmax ? d.st[i].Tin : Tmax;
+    const int Tp = (Tmax + 3) & ~3;
+    const int nh = NT / (d.E / 4);
+    size_t n = 2 * d.A + 3 * Tp + NT + (size_t)nh * d.E;
+    if (d.kind == 1) n += (size_t)d.F * 2 * d.Kc + (size_t)d.A * (d.F + 1) + (size_t)Tmax * (d.F + 1) + 2 * (size_t)(Tmax + d.Kc - 1);
+    return n * sizeof(float);
+}
+
+int attention_step_fwd(const AttnStepDesc& d, hipStream_t s) {
+    T2_REQUIRE(d.nstreams >= 1 && d.nstreams <= 2, "attention_step: nstreams=%d", d.nstreams);
+    T2_REQUIRE(d.A % 4 == 0 && d.A <= NT, "attention_step: attention_dim %d must be a multiple of 4 and <= %d", d.A, NT);
+    T2_REQUIRE(d.E % 4 == 0 && d.E / 4 <= NT && NT % (d.E / 4) == 0, "attention_step: encoder dim %d unsupported", d.E);
+    T2_REQUIRE(d.kind == 0 || (d.Kc % 2 == 1 && d.F >= 1), "attention_step: bad location layer F=%d Kc=%d", d.F, d.Kc);
+    for (int i = 0; i < d.nstreams; ++i)
+        T2_REQUIRE(((uintptr_t)d.st[i].pm & 15) == 0 && ((uintptr_t)d.st[i].memory & 15) == 0, "attention_step: pm/memory must be 16-byte aligned");
+    const size_t smem = attention_fwd_smem(d);
+    T2_REQUIRE(smem <= 160 * 1024, "attention_step: T_in too long for LDS (%zu bytes)", smem);
+    if (smem > 64 * 1024) {
+        T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_step_fwd_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    }
+    hipLaunchKernelGGL(attention_step_fwd_kernel, dim3(d.B, d.nstreams), dim3(NT), smem, s, d);
+    T2_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace t2

@@ -1,0 +1,368 @@
+// C ABI (include/t2amd.h) and the host-side drivers that sequence the kernels of one decoder
+// pass.  No device allocation, no synchronisation except where the header says so.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/t2amd.h"
+#include "kernels.h"
+
+static thread_local char g_err[512] = "";
+
+void t2_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define T2_TRY(expr)                \
+    do {                            \
+        int rc_ = (expr);           \
+        if (rc_ != 0) return rc_;   \
+    } while (0)
+
+using namespace t2;
+
+namespace {
+
+struct Sizes {
+    int B, T, Tin, Tsub, M, P, E, Ha, Hd, A, WD, WO;
+};
+
+Sizes sizes_of(const t2_dims& d, int B, int T, int Tin, int Tsub) {
+    Sizes z{};
+    z.B = B; z.T = T; z.Tin = Tin; z.Tsub = Tsub;
+    z.M = d.n_mel; z.P = d.prenet_dim; z.E = d.enc_dim; z.Ha = d.att_rnn_dim; z.Hd = d.dec_rnn_dim; z.A = d.att_dim;
+    z.WD = 2 * z.Ha + 2 * z.E;
+    z.WO = z.Hd + 2 * z.E;
+    return z;
+}
+
+int check_dims(const t2_dims& d) {
+    T2_REQUIRE(d.n_mel % 4 == 0, "n_mel %d must be a multiple of 4", d.n_mel);
+    T2_REQUIRE(d.prenet_dim % 64 == 0 && d.enc_dim % 64 == 0 && d.att_rnn_dim % 64 == 0 && d.dec_rnn_dim % 64 == 0,
+               "prenet/encoder/rnn dims must be multiples of 64 (got %d %d %d %d)", d.prenet_dim, d.enc_dim, d.att_rnn_dim, d.dec_rnn_dim);
+    T2_REQUIRE(d.att_dim % 4 == 0 && d.att_dim <= 256, "attention_dim %d unsupported", d.att_dim);
+    T2_REQUIRE(d.attention_kind == T2_ATTN_SMA || d.attention_kind == T2_ATTN_LSA, "unknown attention kind %d", d.attention_kind);
+    return 0;
+}
+
+size_t align4(size_t n) { return (n + 3) & ~(size_t)3; }
+
+void layout_of(const t2_dims& d, const Sizes& z, t2_decoder_layout* L) {
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += align4(n); return o; };
+    const size_t BT = (size_t)z.B * z.T;
+    L->x = take(BT * z.M);
+    L->p1 = take(BT * z.P); L->p2 = take(BT * z.P); L->p1s = take(BT * z.P); L->p2s = take(BT * z.P);
+    L->pm = take((size_t)z.B * z.Tin * z.A); L->pms = take((size_t)z.B * z.Tsub * z.A);
+    L->prea = take(BT * 4 * z.Ha); L->preas = take(BT * 4 * z.Ha);
+    L->ga = take(BT * 4 * z.Ha); L->gas = take(BT * 4 * z.Ha);
+    L->cna = take(BT * z.Ha); L->cnas = take(BT * z.Ha); L->ca = take(BT * z.Ha); L->cas = take(BT * z.Ha);
+    L->din = take(BT * z.WD);
+    L->psel = take(BT * z.Tin); L->psels = take(BT * z.Tsub);
+    L->wcum = take(BT * z.Tin); L->wcums = take(BT * z.Tsub);
+    L->pred = take(BT * 4 * z.Hd); L->gd = take(BT * 4 * z.Hd);
+    L->cnd = take(BT * z.Hd); L->cd = take(BT * z.Hd);
+    L->dout = take(BT * z.WO);
+    L->qpart = take((size_t)2 * (z.Ha / 8) * z.B * z.A);
+    L->gemm_ws_floats = (size_t)16 << 20;                     // 64 MiB of split-K scratch
+    L->gemm_ws = take(L->gemm_ws_floats);
+    L->total_floats = off;
+}
+
+struct Dec {
+    const t2_dims& d; const t2_decoder_weights& w; Sizes z; t2_decoder_layout L; float* ws;
+    const float* memory; const float* memory_sub; const int32_t* len; const int32_t* len_sub;
+    float* mel_out; float* gate_out; float* align; float* align_sub;
+    bool training; bool prenet_dropout; bool teacher; uint64_t seed; hipStream_t s;
+    float* P(size_t off) const { return ws + off; }
+};
+
+GemmDesc linear(const float* X, long ldx, const float* W, long ldw, float* Y, long ldy, int M, int N, int K) {
+    GemmDesc g = gemm_desc();
+    g.A = X; g.sam = ldx; g.sak = 1;
+    g.B = W; g.sbn = ldw; g.sbk = 1;
+    g.C = Y; g.ldc = ldy; g.M = M; g.N = N; g.K = K;
+    return g;
+}
+
+// prenet for rows [row0, row0+rows) of the [B,T] grid.  teacher: all B*T rows at once.
+int prenet(const Dec& c, bool sub, const float* X, long ldx, int M, float* P1, float* P2, long ldp, uint32_t base, uint32_t mstride) {
+    const Sizes& z = c.z;
+    GemmDesc g = linear(X, ldx, sub ? c.w.prenet_sub_w1 : c.w.prenet_w1, z.M, P1, ldp, M, z.P, z.M);
+    g.act = ACT_RELU;
+    if (c.prenet_dropout) {
+        g.drop_p = c.d.p_prenet_dropout; g.seed = c.seed; g.site = sub ? T2_SITE_PRENET1_SUB : T2_SITE_PRENET1;
+        g.drop_base = base; g.drop_mstride = mstride;
+    }
+    T2_TRY(gemm(g, c.s));
+    GemmDesc h = linear(P1, ldp, sub ? c.w.prenet_sub_w2 : c.w.prenet_w2, z.P, P2, ldp, M, z.P, z.P);
+    h.act = ACT_RELU;
+    if (c.prenet_dropout) {
+        h.drop_p = c.d.p_prenet_dropout; h.seed = c.seed; h.site = sub ? T2_SITE_PRENET2_SUB : T2_SITE_PRENET2;
+        h.drop_base = base; h.drop_mstride = mstride;
+    }
+    return gemm(h, c.s);
+}
+
+int att_lstm_step(const Dec& c, int t) {
+    const Sizes& z = c.z; const t2_decoder_layout& L = c.L;
+    LstmStepDesc d{};
+    d.nstreams = 2; d.B = z.B; d.H = z.Ha; d.seed = c.seed;
+    d.drop_p = c.training ? c.d.p_att_dropout : 0.f;
+    const long ldD = (long)z.T * z.WD, ldH = (long)z.T * z.Ha, ldG = (long)z.T * 4 * z.Ha, ldP = (long)z.T * z.P;
+    for (int s = 0; s < 2; ++s) {
+        LstmStream& st = d.st[s];
+        const t2_lstm_weights& lw = s ? c.w.att_sub : c.w.att;
+        const int hoff = s ? z.Ha + z.E : 0, coff = hoff + z.Ha;
+        float* DIN = c.P(L.din);
+        int n = 0;
+        if (!c.teacher) {
+            st.seg[n++] = LstmSeg{c.P(s ? L.p2s : L.p2) + (long)t * z.P, ldP, lw.w_ih, (long)(z.P + z.E), z.P};
+            st.bias1 = lw.b_ih; st.bias2 = lw.b_hh;
+        } else {
+            st.pre = c.P(s ? L.preas : L.prea) + (long)t * 4 * z.Ha; st.ldpre = ldG;
+        }
+        if (t > 0) {
+            st.seg[n++] = LstmSeg{DIN + (long)(t - 1) * z.WD + coff, ldD, lw.w_ih + z.P, (long)(z.P + z.E), z.E};
+            st.seg[n++] = LstmSeg{DIN + (long)(t - 1) * z.WD + hoff, ldD, lw.w_hh, (long)z.Ha, z.Ha};
+            st.c_prev = c.P(s ? L.cas : L.ca) + (long)(t - 1) * z.Ha; st.ldc_prev = ldH;
+        }
+        st.nseg = n;
+        st.gates = c.P(s ? L.gas : L.ga) + (long)t * 4 * z.Ha; st.ldgates = ldG;
+        st.c_new = c.P(s ? L.cnas : L.cna) + (long)t * z.Ha; st.ldc_new = ldH;
+        st.c_out = c.P(s ? L.cas : L.ca) + (long)t * z.Ha; st.ldc_out = ldH;
+        st.h_out = DIN + (long)t * z.WD + hoff; st.ldh_out = ldD;
+        st.site_h = s ? T2_SITE_ATT_H_SUB : T2_SITE_ATT_H; st.site_c = s ? T2_SITE_ATT_C_SUB : T2_SITE_ATT_C;
+        st.idx_base = (uint32_t)t * z.Ha; st.idx_bstride = (uint32_t)z.T * z.Ha;
+        st.wq = s ? c.w.attn_sub.wq : c.w.attn.wq; st.A = z.A;
+        st.qpart = c.P(L.qpart) + (size_t)s * (z.Ha / 8) * z.B * z.A;
+    }
+    return lstm_step_fwd(d, c.s);
+}
+
+int attention_step(const Dec& c, int t) {
+    const Sizes& z = c.z; const t2_decoder_layout& L = c.L;
+    AttnStepDesc d{};
+    d.nstreams = 2; d.B = z.B; d.A = z.A; d.E = z.E; d.kind = c.d.attention_kind;
+    d.F = c.d.loc_filters; d.Kc = c.d.loc_kernel; d.seed = c.seed; d.first = t == 0;
+    d.noise_std = (c.training && d.kind == T2_ATTN_SMA) ? 2.0f : 0.f;     // attention.py:315,346-348
+    d.mask_value = -INFINITY;                                              // attention.py:37,306
+    const long ldD = (long)z.T * z.WD, ldO = (long)z.T * z.WO;
+    for (int s = 0; s < 2; ++s) {
+        AttnStream& st = d.st[s];
+        const t2_attention_weights& aw = s ? c.w.attn_sub : c.w.attn;
+        const int Tin = s ? z.Tsub : z.Tin;
+        float* al = s ? c.align_sub : c.align;
+        const long ldA = (long)z.T * Tin;
+        st.Tin = Tin;
+        st.qpart = c.P(L.qpart) + (size_t)s * (z.Ha / 8) * z.B * z.A; st.nparts = z.Ha / 8;
+        st.pm = c.P(s ? L.pms : L.pm); st.memory = s ? c.memory_sub : c.memory;
+        st.lengths = s ? c.len_sub : c.len;
+        st.a_prev = t > 0 ? al + (long)(t - 1) * Tin : nullptr; st.lda_prev = ldA;
+        st.a_out = al + (long)t * Tin; st.lda_out = ldA;
+        if (d.kind == T2_ATTN_SMA) {
+            st.p_out = c.P(s ? L.psels : L.psel) + (long)t * Tin; st.ldp_out = ldA;
+        } else {
+            float* wc = c.P(s ? L.wcums : L.wcum);
+            st.wcum_prev = t > 0 ? wc + (long)(t - 1) * Tin : nullptr; st.ldwcum_prev = ldA;
+            st.wcum_out = wc + (long)t * Tin; st.ldwcum_out = ldA;
+        }
+        st.ctx1 = c.P(L.din) + (long)t * z.WD + (s ? 2 * z.Ha + z.E : z.Ha); st.ldctx1 = ldD;
+        st.ctx2 = c.P(L.dout) + (long)t * z.WO + z.Hd + (s ? z.E : 0); st.ldctx2 = ldO;
+        st.v = aw.v; st.loc_conv = aw.loc_conv; st.loc_dense = aw.loc_dense;
+        st.site_noise = s ? T2_SITE_NOISE_SUB : T2_SITE_NOISE;
+        st.idx_base = (uint32_t)t * Tin; st.idx_bstride = (uint32_t)z.T * Tin;
+    }
+    return attention_step_fwd(d, c.s);
+}
+
+int dec_lstm_step(const Dec& c, int t) {
+    const Sizes& z = c.z; const t2_decoder_layout& L = c.L;
+    LstmStepDesc d{};
+    d.nstreams = 1; d.B = z.B; d.H = z.Hd; d.seed = c.seed;
+    d.drop_p = c.training ? c.d.p_dec_dropout : 0.f;
+    const long ldO = (long)z.T * z.WO, ldH = (long)z.T * z.Hd, ldG = (long)z.T * 4 * z.Hd;
+    LstmStream& st = d.st[0];
+    int n = 0;
+    if (!c.teacher) {
+        st.seg[n++] = LstmSeg{c.P(L.din) + (long)t * z.WD, (long)z.T * z.WD, c.w.dec.w_ih, (long)z.WD, z.WD};
+        st.bias1 = c.w.dec.b_ih; st.bias2 = c.w.dec.b_hh;
+    } else {
+        st.pre = c.P(L.pred) + (long)t * 4 * z.Hd; st.ldpre = ldG;
+    }
+    if (t > 0) {
+        st.seg[n++] = LstmSeg{c.P(L.dout) + (long)(t - 1) * z.WO, ldO, c.w.dec.w_hh, (long)z.Hd, z.Hd};
+        st.c_prev = c.P(L.cd) + (long)(t - 1) * z.Hd; st.ldc_prev = ldH;
+    }
+    st.nseg = n;
+    st.gates = c.P(L.gd) + (long)t * 4 * z.Hd; st.ldgates = ldG;
+    st.c_new = c.P(L.cnd) + (long)t * z.Hd; st.ldc_new = ldH;
+    st.c_out = c.P(L.cd) + (long)t * z.Hd; st.ldc_out = ldH;
+    st.h_out = c.P(L.dout) + (long)t * z.WO; st.ldh_out = ldO;
+    st.site_h = T2_SITE_DEC_H; st.site_c = T2_SITE_DEC_C;
+    st.idx_base = (uint32_t)t * z.Hd; st.idx_bstride = (uint32_t)z.T * z.Hd;
+    return lstm_step_fwd(d, c.s);
+}
+
+// mel / gate projection for rows t0 .. of the [B,T] grid (model.py:382-388)
+int projection(const Dec& c, const float* X, long ldx, int M, float* mel, long ldmel, float* gate, long ldgate) {
+    const Sizes& z = c.z;
+    GemmDesc g = linear(X, ldx, c.w.proj_w, z.WO, mel, ldmel, M, z.M, z.WO);
+    g.bias1 = c.w.proj_b;
+    T2_TRY(gemm(g, c.s));
+    GemmDesc h = linear(X, ldx, c.w.gate_w, z.WO, gate, ldgate, M, 1, z.WO);
+    h.bias1 = c.w.gate_b;
+    return gemm(h, c.s);
+}
+
+int processed_memory(const Dec& c) {
+    const Sizes& z = c.z;
+    GemmDesc g = linear(c.memory, z.E, c.w.attn.wm, z.E, c.P(c.L.pm), z.A, z.B * z.Tin, z.A, z.E);
+    T2_TRY(gemm(g, c.s));
+    GemmDesc h = linear(c.memory_sub, z.E, c.w.attn_sub.wm, z.E, c.P(c.L.pms), z.A, z.B * z.Tsub, z.A, z.E);
+    return gemm(h, c.s);
+}
+
+__global__ void stop_check_kernel(const float* gate, long ldgate, int t, int B, float thr, int32_t* stop_index, int32_t* done) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && stop_index[b] < 0) {
+        const float g = gate[(long)b * ldgate + t];
+        if (1.0f / (1.0f + expf(-g)) > thr) { stop_index[b] = t; atomicAdd(done, 1); }
+    }
+}
+__global__ void init_stop_kernel(int32_t* stop_index, int32_t* done, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) stop_index[b] = -1;
+    if (b == 0) *done = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* t2_last_error(void) { return g_err; }
+int t2_version(void) { return 1; }
+
+int t2_decoder_layout_query(const t2_dims* dims, int B, int T, int Tin, int Tsub, t2_decoder_layout* out) {
+    T2_REQUIRE(dims && out, "null argument");
+    T2_TRY(check_dims(*dims));
+    T2_REQUIRE(B >= 1 && B <= 256 && T >= 1 && Tin >= 1 && Tsub >= 1, "bad shape B=%d T=%d Tin=%d Tsub=%d", B, T, Tin, Tsub);
+    layout_of(*dims, sizes_of(*dims, B, T, Tin, Tsub), out);
+    return 0;
+}
+
+int t2_decoder_forward(const t2_dims* dims, const t2_decoder_weights* w, const t2_decoder_fwd_args* a, void* stream) {
+    T2_REQUIRE(dims && w && a, "null argument");
+    T2_TRY(check_dims(*dims));
+    T2_REQUIRE(a->B >= 1 && a->B <= 256 && a->T >= 1, "bad shape B=%d T=%d", a->B, a->T);
+    T2_REQUIRE((long)a->B * a->T * 4 * dims->att_rnn_dim < (1l << 32), "B*T too large for 32-bit RNG indices");
+    Dec c{*dims, *w, sizes_of(*dims, a->B, a->T, a->Tin, a->Tsub), {}, a->ws,
+          a->memory, a->memory_sub, a->mem_lengths, a->sub_lengths,
+          a->mel_out, a->gate_out, a->align, a->align_sub,
+          a->training != 0, a->prenet_dropout != 0, true, a->seed, (hipStream_t)stream};
+    layout_of(*dims, c.z, &c.L);
+    const Sizes& z = c.z; const t2_decoder_layout& L = c.L;
+    const int BT = z.B * z.T;
+
+    // teacher inputs and both prenets over all frames (model.py:407-413)
+    T2_TRY(teacher_inputs(a->mels, c.P(L.x), z.B, z.M, z.T, c.s));
+    T2_TRY(prenet(c, false, c.P(L.x), z.M, BT, c.P(L.p1), c.P(L.p2), z.P, 0, 0));
+    T2_TRY(prenet(c, true, c.P(L.x), z.M, BT, c.P(L.p1s), c.P(L.p2s), z.P, 0, 0));
+    T2_TRY(processed_memory(c));                                    // model.py:258,261
+    // hoisted input half of both attention LSTMs:  P2 . W_ih[:, :P]^T + b_ih + b_hh
+    for (int s = 0; s < 2; ++s) {
+        const t2_lstm_weights& lw = s ? w->att_sub : w->att;
+        GemmDesc g = linear(c.P(s ? L.p2s : L.p2), z.P, lw.w_ih, z.P + z.E, c.P(s ? L.preas : L.prea), 4 * z.Ha, BT, 4 * z.Ha, z.P);
+        g.bias1 = lw.b_ih; g.bias2 = lw.b_hh;
+        T2_TRY(gemm(g, c.s));
+    }
+    // serial loop A: attention LSTMs + attention (the only truly recurrent chain through the contexts)
+    for (int t = 0; t < z.T; ++t) {
+        T2_TRY(att_lstm_step(c, t));
+        T2_TRY(attention_step(c, t));
+    }
+    // hoisted input half of the decoder LSTM over all frames:  [att_h|ctx|att_h_sub|ctx_sub] . W_ih^T + b
+    {
+        GemmDesc g = linear(c.P(L.din), z.WD, w->dec.w_ih, z.WD, c.P(L.pred), 4 * z.Hd, BT, 4 * z.Hd, z.WD);
+        g.bias1 = w->dec.b_ih; g.bias2 = w->dec.b_hh;
+        T2_TRY(gemm(g, c.s));
+    }
+    // serial loop B: decoder LSTM recurrence
+    for (int t = 0; t < z.T; ++t) T2_TRY(dec_lstm_step(c, t));
+    // projections over all frames
+    return projection(c, c.P(L.dout), z.WO, BT, a->mel_out, z.M, a->gate_out, 1);
+}
+
+int t2_decoder_infer(const t2_dims* dims, const t2_decoder_weights* w, const t2_decoder_infer_args* a, void* stream) {
+    T2_REQUIRE(dims && w && a && a->steps_run_host, "null argument");
+    T2_TRY(check_dims(*dims));
+    T2_REQUIRE(a->B >= 1 && a->B <= 256 && a->max_steps >= 1, "bad shape B=%d max_steps=%d", a->B, a->max_steps);
+    Dec c{*dims, *w, sizes_of(*dims, a->B, a->max_steps, a->Tin, a->Tsub), {}, a->ws,
+          a->memory, a->memory_sub, a->mem_lengths, a->sub_lengths,
+          a->mel_out, a->gate_out, a->align, a->align_sub,
+          false, a->prenet_dropout != 0, false, a->seed, (hipStream_t)stream};
+    layout_of(*dims, c.z, &c.L);
+    const Sizes& z = c.z; const t2_decoder_layout& L = c.L;
+    const int T = z.T;
+    const int poll = a->poll_every > 0 ? a->poll_every : 16;
+
+    hipLaunchKernelGGL(init_stop_kernel, dim3((z.B + 63) / 64), dim3(64), 0, c.s, a->stop_index, a->done_count, z.B);
+    T2_LAUNCH_CHECK();
+    T2_TRY(fill_f32(c.P(L.x), 0.f, (size_t)z.B * z.M, c.s));      // go frame (model.py:444-445), rows [B][M] contiguous
+    T2_TRY(processed_memory(c));
+    int steps = 0;
+    for (int t = 0; t < T; ++t) {
+        // prenet of the previous output frame (model.py:449-450,470-471)
+        const float* X = t == 0 ? c.P(L.x) : a->mel_out + (long)(t - 1) * z.M;
+        const long ldx = t == 0 ? z.M : (long)T * z.M;
+        const uint32_t base = (uint32_t)t * z.P, mstride = (uint32_t)T * z.P;
+        T2_TRY(prenet(c, false, X, ldx, z.B, c.P(L.p1) + (long)t * z.P, c.P(L.p2) + (long)t * z.P, (long)T * z.P, base, mstride));
+        T2_TRY(prenet(c, true, X, ldx, z.B, c.P(L.p1s) + (long)t * z.P, c.P(L.p2s) + (long)t * z.P, (long)T * z.P, base, mstride));
+        T2_TRY(att_lstm_step(c, t));
+        T2_TRY(attention_step(c, t));
+        T2_TRY(dec_lstm_step(c, t));
+        T2_TRY(projection(c, c.P(L.dout) + (long)t * z.WO, (long)T * z.WO, z.B, a->mel_out + (long)t * z.M, (long)T * z.M,
+                          a->gate_out + t, T));
+        hipLaunchKernelGGL(stop_check_kernel, dim3((z.B + 63) / 64), dim3(64), 0, c.s, a->gate_out, (long)T, t, z.B,
+                           a->gate_threshold, a->stop_index, a->done_count);
+        T2_LAUNCH_CHECK();
+        steps = t + 1;
+        if (steps % poll == 0 || steps == T) {
+            int32_t done = 0;
+            T2_CHECK_HIP(hipMemcpyAsync(&done, a->done_count, sizeof(done), hipMemcpyDeviceToHost, c.s));
+            T2_CHECK_HIP(hipStreamSynchronize(c.s));
+            if (done >= z.B) break;
+        }
+    }
+    *a->steps_run_host = steps;
+    return 0;
+}
+
+int t2_finalize_bct(const float* in_btc, float* out_bct, int B, int T, int C, const int32_t* lengths, float fill, void* stream) {
+    return transpose_btc_to_bct(in_btc, out_bct, B, T, C, lengths, fill, (hipStream_t)stream);
+}
+int t2_mask_bt(float* x, int B, int T, const int32_t* lengths, float fill, void* stream) {
+    T2_REQUIRE(lengths, "t2_mask_bt: lengths is null");
+    return mask_bt(x, B, T, lengths, fill, (hipStream_t)stream);
+}
+
+int t2_gemm(const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak, long sbn, long sbk, long ldc,
+            const float* bias, int act, float alpha, float beta, float* ws, size_t ws_bytes, int splitk, void* stream) {
+    GemmDesc g = gemm_desc();
+    g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
+    g.sam = sam; g.sak = sak; g.sbn = sbn; g.sbk = sbk; g.ldc = ldc;
+    g.bias1 = bias; g.act = act; g.alpha = alpha; g.beta = beta;
+    g.ws = ws; g.ws_bytes = ws_bytes; g.splitk = splitk;
+    return gemm(g, (hipStream_t)stream);
+}
+int t2_rng_keep_mask(uint64_t seed, uint32_t site, uint32_t n, float p, uint8_t* out, void* stream) {
+    return rng_keep_mask(seed, site, n, p, out, (hipStream_t)stream);
+}
+int t2_rng_normal(uint64_t seed, uint32_t site, uint32_t n, float* out, void* stream) {
+    return rng_normal(seed, site, n, out, (hipStream_t)stream);
+}
+
+}  // extern "C"

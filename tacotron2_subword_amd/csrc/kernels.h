@@ -1,0 +1,89 @@
+// Internal launcher interface between the C-ABI layer (c_api.hip) and the kernel files.
+// Everything takes raw device pointers and enqueues on the given stream; nothing allocates
+// or synchronises.
+#pragma once
+#include "common.h"
+
+namespace t2 {
+
+// ------------------------------------------------------------------ GEMM (gemm.hip)
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
+
+struct GemmDesc {
+    const float* A; const float* B; float* C;
+    int M, N, K;
+    long sam, sak;      // A(m,k) = A[m*sam + k*sak]   (one of the two strides must be 1)
+    long sbn, sbk;      // B(k,n) = B[n*sbn + k*sbk]   (one of the two strides must be 1)
+    long ldc;           // C(m,n) = C[m*ldc + n]
+    int batch; long bsA, bsB, bsC;
+    float alpha, beta;  // C = act(alpha*A.B + bias1 + bias2) [dropout] + beta*C_old
+    const float* bias1; const float* bias2;   // per-n, nullable
+    int act;
+    float drop_p; uint64_t seed; uint32_t site;   // dropout keep-bit index = drop_base + m*drop_mstride + n (batch==1 only)
+    uint32_t drop_base, drop_mstride;             // drop_mstride 0 -> N
+    float* ws; size_t ws_bytes;                   // split-K scratch (nullable -> no split)
+    int splitk;                                   // 0 = choose automatically
+};
+inline GemmDesc gemm_desc() {
+    GemmDesc d{}; d.batch = 1; d.alpha = 1.f; d.beta = 0.f; d.act = ACT_NONE; d.drop_p = 0.f; return d;
+}
+int gemm(const GemmDesc& d, hipStream_t s);
+
+// ------------------------------------------------------------------ LSTM (lstm.hip)
+constexpr int kMaxSeg = 6;
+struct LstmSeg { const float* x; long ldx; const float* w; long ldw; int k; };
+struct LstmStream {
+    LstmSeg seg[kMaxSeg]; int nseg;
+    const float* pre; long ldpre;         // [B,4H] input-side pre-activations (nullable)
+    const float* bias1; const float* bias2;   // [4H] nullable (added when given)
+    const float* c_prev; long ldc_prev;   // [B,H]
+    float* gates; long ldgates;           // [B,4H] activated i,f,g,o (nullable)
+    float* c_new; long ldc_new;           // [B,H] cell before dropout (nullable)
+    float* h_out; long ldh_out;           // [B,H] after dropout
+    float* h_out2; long ldh_out2;         // optional second copy of h (nullable)
+    float* c_out; long ldc_out;           // [B,H] after dropout
+    uint32_t site_h, site_c; uint32_t idx_base, idx_bstride;   // dropout index = idx_base + b*idx_bstride + u
+    const int* lengths; int t;            // packed sequences: item active iff t < lengths[b] (nullable);
+                                          // an inactive item writes zeros (state and output)
+    const float* wq; int A; float* qpart; // optional fused query partials: qpart[H/8][B][A] (wq: [A,H])
+};
+constexpr int kMaxLstmStreams = 4;
+struct LstmStepDesc { LstmStream st[kMaxLstmStreams]; int nstreams; int B, H; float drop_p; uint64_t seed; };
+int lstm_step_fwd(const LstmStepDesc& d, hipStream_t s);
+
+// ------------------------------------------------------------------ attention (attention.hip)
+struct AttnStream {
+    const float* query; long ldq;         // [B,A] processed query (W_q h), or null when qpart is given
+    const float* qpart; int nparts;       // [nparts][B][A] partial queries from lstm_step_fwd (summed in order)
+    const float* pm;                      // [B,Tin,A] processed memory
+    const float* memory;                  // [B,Tin,E]
+    const int* lengths;                   // [B] valid memory length (nullable = all valid)
+    const float* a_prev; long lda_prev;   // [B,Tin] previous alignment / weights (nullable at t=0 -> init)
+    float* a_out; long lda_out;           // [B,Tin] new alignment / weights
+    float* p_out; long ldp_out;           // [B,Tin] SMA selection probability (nullable)
+    const float* wcum_prev; long ldwcum_prev;   // LSA cumulative weights before this step (null at the first step)
+    float* wcum_out; long ldwcum_out;           // LSA cumulative weights after this step (nullable for SMA)
+    float* ctx1; long ldctx1;             // [B,E]
+    float* ctx2; long ldctx2;             // second destination (nullable)
+    const float* v;                       // [A]
+    const float* loc_conv; const float* loc_dense;   // LSA: [F,2,Kc], [A,F]
+    uint32_t site_noise; uint32_t idx_base, idx_bstride;   // SMA noise index = idx_base + b*idx_bstride + j
+    int Tin;
+};
+struct AttnStepDesc {
+    AttnStream st[2]; int nstreams; int B, A, E; int kind;   // kind 0 = SMA, 1 = LSA
+    int F, Kc; float noise_std; uint64_t seed; float mask_value; int first;
+};
+int attention_step_fwd(const AttnStepDesc& d, hipStream_t s);
+
+// ------------------------------------------------------------------ elementwise (elementwise.hip)
+int rng_keep_mask(uint64_t seed, uint32_t site, uint32_t n, float p, uint8_t* out, hipStream_t s);
+int rng_normal(uint64_t seed, uint32_t site, uint32_t n, float* out, hipStream_t s);
+// X[b,t,:] = (t == 0) ? 0 : mel[b,:,t-1]   (go frame + teacher forcing shift; mel is [B,M,T])
+int teacher_inputs(const float* mel, float* X, int B, int M, int T, hipStream_t s);
+// out[b,c,t] = in[b,t,c] with optional padding fill for t >= lengths[b]
+int transpose_btc_to_bct(const float* in, float* out, int B, int T, int C, const int* lengths, float fill, hipStream_t s);
+int mask_bt(float* x, int B, int T, const int* lengths, float fill, hipStream_t s);
+int fill_f32(float* p, float v, size_t n, hipStream_t s);
+
+}  // namespace t2

@@ -1,0 +1,110 @@
+"""Host-side wrappers over the C ABI: allocate outputs/workspaces as torch tensors, pass raw
+device pointers, enqueue on torch's current stream.  No arithmetic happens here."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+def _i32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else t.to(dtype=torch.int32).contiguous()
+
+
+def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bool = True, bias=None, act: int = 0,
+         alpha: float = 1.0, beta: float = 0.0, out: Optional[torch.Tensor] = None, splitk: int = 0,
+         ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = act(alpha * op(A) @ op(B) + bias) + beta*C with op(A) = A[M,K] (or A[K,M]^T) and
+    op(B) = B[N,K]^T (trans_b, nn.Linear weight layout) or B[K,N]."""
+    M, K = (A.shape[1], A.shape[0]) if trans_a else A.shape
+    N = B.shape[0] if trans_b else B.shape[1]
+    sam, sak = (1, A.stride(0)) if trans_a else (A.stride(0), 1)
+    sbn, sbk = (B.stride(0), 1) if trans_b else (1, B.stride(0))
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    L.check(L.lib().t2_gemm(L.ptr(A), L.ptr(B), L.ptr(out), M, N, K, sam, sak, sbn, sbk, out.stride(0), L.ptr(bias), act,
+                            alpha, beta, L.ptr(ws), 0 if ws is None else ws.numel() * 4, splitk, L.stream()))
+    return out
+
+
+def rng_keep_mask(seed: int, site: int, n: int, p: float, device="cuda") -> torch.Tensor:
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    L.check(L.lib().t2_rng_keep_mask(seed, site, n, p, L.ptr(out), L.stream()))
+    return out
+
+
+def rng_normal(seed: int, site: int, n: int, device="cuda") -> torch.Tensor:
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    L.check(L.lib().t2_rng_normal(seed, site, n, L.ptr(out), L.stream()))
+    return out
+
+
+class DecoderPass:
+    """Outputs + saved-activation workspace of one teacher-forced decoder pass."""
+
+    def __init__(self, dims, B, T, Tin, Tsub, device):
+        self.dims, self.B, self.T, self.Tin, self.Tsub = dims, B, T, Tin, Tsub
+        self.layout = L.decoder_layout(dims, B, T, Tin, Tsub)
+        self.ws = torch.empty(self.layout.total_floats, dtype=torch.float32, device=device)
+        self.mel = torch.empty(B, T, dims.n_mel, dtype=torch.float32, device=device)
+        self.gate = torch.empty(B, T, dtype=torch.float32, device=device)
+        self.align = torch.empty(B, T, Tin, dtype=torch.float32, device=device)
+        self.align_sub = torch.empty(B, T, Tsub, dtype=torch.float32, device=device)
+
+    def view(self, name: str, *shape) -> torch.Tensor:
+        off = getattr(self.layout, name)
+        n = 1
+        for s in shape:
+            n *= s
+        return self.ws[off:off + n].view(*shape)
+
+
+def decoder_forward(W: L.DecoderWeights, dims: L.Dims, memory, memory_sub, mem_lengths, sub_lengths, mels, *,
+                    training: bool, prenet_dropout: bool, seed: int, keep=None) -> DecoderPass:
+    """Teacher-forced decoder (Decoder.forward, model.py:392-428).  mels: [B,n_mel,T]."""
+    B, Tin, _ = memory.shape
+    Tsub, T = memory_sub.shape[1], mels.shape[2]
+    dp = DecoderPass(dims, B, T, Tin, Tsub, memory.device)
+    ml, sl = _i32(mem_lengths), _i32(sub_lengths)
+    a = L.DecoderFwdArgs(B, T, Tin, Tsub, L.ptr(memory), L.ptr(memory_sub), L.ptr(ml), L.ptr(sl), L.ptr(mels),
+                         L.ptr(dp.mel), L.ptr(dp.gate), L.ptr(dp.align), L.ptr(dp.align_sub), L.ptr(dp.ws),
+                         int(training), int(prenet_dropout), seed)
+    L.check(L.lib().t2_decoder_forward(C.byref(dims), C.byref(W), C.byref(a), L.stream()))
+    dp._keep = (ml, sl, keep)
+    return dp
+
+
+def decoder_infer(W: L.DecoderWeights, dims: L.Dims, memory, memory_sub, *, max_steps: int, gate_threshold: float,
+                  prenet_dropout: bool, seed: int = 0, poll_every: int = 16, mem_lengths=None, sub_lengths=None):
+    """Autoregressive decode (Decoder.inference, model.py:430-492) for any B.
+    Returns (DecoderPass sized for max_steps, steps_run, stop_index[B] (int32, -1 = never stopped))."""
+    B, Tin, _ = memory.shape
+    Tsub = memory_sub.shape[1]
+    dp = DecoderPass(dims, B, max_steps, Tin, Tsub, memory.device)
+    stop = torch.empty(B, dtype=torch.int32, device=memory.device)
+    done = torch.empty(1, dtype=torch.int32, device=memory.device)
+    steps = C.c_int(0)
+    ml, sl = _i32(mem_lengths), _i32(sub_lengths)
+    a = L.DecoderInferArgs(B, Tin, Tsub, max_steps, poll_every, gate_threshold, L.ptr(memory), L.ptr(memory_sub),
+                           L.ptr(ml), L.ptr(sl), L.ptr(dp.mel), L.ptr(dp.gate), L.ptr(dp.align), L.ptr(dp.align_sub),
+                           L.ptr(stop), L.ptr(done), L.ptr(dp.ws), int(prenet_dropout), seed, C.pointer(steps))
+    L.check(L.lib().t2_decoder_infer(C.byref(dims), C.byref(W), C.byref(a), L.stream()))
+    return dp, steps.value, stop
+
+
+def finalize_bct(x_btc: torch.Tensor, lengths: Optional[torch.Tensor], fill: float) -> torch.Tensor:
+    """[B,T,C] -> [B,C,T] with frames >= length set to `fill` (parse_output, model.py:531-541)."""
+    B, T, Cc = x_btc.shape
+    out = torch.empty(B, Cc, T, dtype=torch.float32, device=x_btc.device)
+    ln = _i32(lengths)
+    L.check(L.lib().t2_finalize_bct(L.ptr(x_btc), L.ptr(out), B, T, Cc, L.ptr(ln), fill, L.stream()))
+    return out
+
+
+def mask_bt_(x: torch.Tensor, lengths: torch.Tensor, fill: float) -> torch.Tensor:
+    ln = _i32(lengths)
+    L.check(L.lib().t2_mask_bt(L.ptr(x), x.shape[0], x.shape[1], L.ptr(ln), fill, L.stream()))
+    return x

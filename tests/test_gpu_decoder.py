@@ -1,0 +1,167 @@
+"""GPU parity of the HIP decoder (teacher-forced and autoregressive) against the CPU oracle and
+against the golden vectors recorded from the reference.  Tolerance is the north-star contract:
+mel / gate max-abs error < 1e-4 in fp32, stop-frame index bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import recipe
+from oracle import tacotron2_oracle as O
+
+from helpers import LSA, SMA, hp_for, load_golden, maxabs, oracle_memories, tiny_hp, to_dev
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def env():
+    from tacotron2_subword_amd import _lib as L
+    from tacotron2_subword_amd import ops
+    return L, ops
+
+
+def run_hip_decoder(env, P, hp, mem, mem_sub, tl, bl, mels, training=False, prenet_dropout=False, seed=0):
+    L, ops = env
+    dims = L.dims_from_hparams(hp)
+    Pd = to_dev(P)
+    W = L.decoder_weights(Pd, dims.attention_kind)
+    dp = ops.decoder_forward(W, dims, mem.cuda().contiguous(), mem_sub.cuda().contiguous(), tl.cuda(), bl.cuda(),
+                             mels.cuda().contiguous(), training=training, prenet_dropout=prenet_dropout, seed=seed, keep=Pd)
+    torch.cuda.synchronize()
+    return dp
+
+
+@pytest.mark.parametrize("att,name", [(SMA, "sma_small_eval"), (LSA, "lsa_small_eval"), (SMA, "sma_baseline_eval")])
+def test_teacher_forced_vs_golden(env, att, name):
+    g = load_golden(name)
+    B, Tin, Tsub, T, _ = (int(v) for v in g["meta"])
+    hp = hp_for(att)
+    P = recipe.make_weights(hp)
+    x, y = recipe.parse_batch(recipe.make_batch(hp, B, Tin, Tsub, T))
+    mem, mem_sub = torch.from_numpy(g["memory"]), torch.from_numpy(g["memory_sub"])
+    dp = run_hip_decoder(env, P, hp, mem, mem_sub, x[1], x[2], x[3])
+    # golden mel/gate are masked by parse_output; compare the valid frames
+    ol = x[5]
+    mel = dp.mel.cpu().transpose(1, 2)          # [B,80,T]
+    valid = O.get_mask_from_lengths(ol, T)
+    assert maxabs(mel * valid[:, None, :], g["mel"]) < TOL
+    gate = dp.gate.cpu()
+    assert maxabs(torch.where(valid, gate, torch.full_like(gate, 1e3)), g["gate"]) < TOL
+    assert maxabs(dp.align.cpu(), g["align"]) < TOL
+    assert maxabs(dp.align_sub.cpu(), g["align_bert"]) < TOL
+    # recurrent state of the first / last step (nothing drifts over T steps)
+    Ha, E, Hd = hp["attention_rnn_dim"], hp["encoder_embedding_dim"], hp["decoder_rnn_dim"]
+    din = dp.view("din", B, T, 2 * Ha + 2 * E).cpu()
+    assert maxabs(din[:, T - 1, :Ha], g["steplast_att_h"]) < TOL
+    assert maxabs(din[:, T - 1, Ha:Ha + E], g["steplast_ctx"]) < TOL
+    assert maxabs(din[:, 0, Ha + E:2 * Ha + E], g["step0_att_h_bert"]) < TOL
+    dout = dp.view("dout", B, T, Hd + 2 * E).cpu()
+    assert maxabs(dout[:, T - 1, :Hd], g["steplast_dec_h"]) < TOL
+
+
+@pytest.mark.parametrize("att", [SMA, LSA])
+@pytest.mark.parametrize("B", [1, 5, 33])
+def test_teacher_forced_tiny_vs_oracle(env, att, B):
+    """Small dims, ragged lengths, batch sizes around the 32-row MFMA tile edge."""
+    hp = tiny_hp(att)
+    P = recipe.make_weights(hp, seed=3)
+    Tin, Tsub, T = 11, 7, 9
+    x, y = recipe.parse_batch(recipe.make_batch(hp, B, Tin, Tsub, T, seed=B))
+    mem, mem_sub = oracle_memories(P, hp, x)
+    with torch.no_grad():
+        mel, gate, al, alb = O.decoder_forward(mem, mem_sub, x[3], x[1], x[2], P, hp)
+    dp = run_hip_decoder(env, P, hp, mem, mem_sub, x[1], x[2], x[3])
+    assert maxabs(dp.mel.cpu().transpose(1, 2), mel) < TOL
+    assert maxabs(dp.gate.cpu(), gate) < TOL
+    assert maxabs(dp.align.cpu(), al) < TOL
+    assert maxabs(dp.align_sub.cpu(), alb) < TOL
+
+
+@pytest.mark.parametrize("att", [SMA, LSA])
+def test_teacher_forced_training_mode_replay(env, att):
+    """Training mode: dropout keep-bits and SMA noise drawn by the HIP RNG are exported through
+    the C ABI and replayed through the oracle."""
+    L, ops = env
+    hp = hp_for(att)
+    P = recipe.make_weights(hp)
+    B, Tin, Tsub, T = 3, 13, 8, 12
+    seed = 20240607
+    x, y = recipe.parse_batch(recipe.make_batch(hp, B, Tin, Tsub, T))
+    mem, mem_sub = oracle_memories(P, hp, x)
+    Pn, Ha, Hd = hp["prenet_dim"], hp["attention_rnn_dim"], hp["decoder_rnn_dim"]
+    S = L.SITE
+
+    def km(site, p, *shape):        # HIP index order is [B,T,*]; the oracle wants [T,B,*]
+        return ops.rng_keep_mask(seed, S[site], int(np.prod(shape)), p).view(*shape).float().cpu().transpose(0, 1)
+
+    rnd = dict(prenet_keep=[km("PRENET1", 0.5, B, T, Pn), km("PRENET2", 0.5, B, T, Pn)],
+               prenet_bert_keep=[km("PRENET1_SUB", 0.5, B, T, Pn), km("PRENET2_SUB", 0.5, B, T, Pn)],
+               att_h_keep=km("ATT_H", 0.1, B, T, Ha), att_c_keep=km("ATT_C", 0.1, B, T, Ha),
+               att_h_bert_keep=km("ATT_H_SUB", 0.1, B, T, Ha), att_c_bert_keep=km("ATT_C_SUB", 0.1, B, T, Ha),
+               dec_h_keep=km("DEC_H", 0.1, B, T, Hd), dec_c_keep=km("DEC_C", 0.1, B, T, Hd))
+    if att == SMA:
+        rnd["sma_noise"] = ops.rng_normal(seed, S["NOISE"], B * T * Tin).view(B, T, Tin).cpu().transpose(0, 1)
+        rnd["sma_noise_bert"] = ops.rng_normal(seed, S["NOISE_SUB"], B * T * Tsub).view(B, T, Tsub).cpu().transpose(0, 1)
+    with torch.no_grad():
+        mel, gate, al, alb = O.decoder_forward(mem, mem_sub, x[3], x[1], x[2], P, hp, rnd)
+    dp = run_hip_decoder(env, P, hp, mem, mem_sub, x[1], x[2], x[3], training=True, prenet_dropout=True, seed=seed)
+    assert maxabs(dp.mel.cpu().transpose(1, 2), mel) < TOL
+    assert maxabs(dp.gate.cpu(), gate) < TOL
+    assert maxabs(dp.align.cpu(), al) < TOL
+    assert maxabs(dp.align_sub.cpu(), alb) < TOL
+
+
+@pytest.mark.parametrize("att,name", [(SMA, "sma_infer"), (LSA, "lsa_infer")])
+def test_inference_vs_golden(env, att, name):
+    L, ops = env
+    g = load_golden(name)
+    _, Tin, Tsub, steps = (int(v) for v in g["meta"])
+    hp = hp_for(att)
+    P = recipe.make_weights(hp)
+    b = recipe.make_batch(hp, 1, Tin, Tsub, 8, seed=4321, ragged=False)
+    with torch.no_grad():
+        mem = O.front_end(P, hp, b[0], None, b[7], "phone", False)
+        mem_sub = O.front_end(P, hp, b[6], None, b[8], "sub", False)
+    dims = L.dims_from_hparams(hp)
+    Pd = to_dev(P)
+    W = L.decoder_weights(Pd, dims.attention_kind)
+    # fixed-length run: the stop never fires
+    dp, n, stop = ops.decoder_infer(W, dims, mem.cuda(), mem_sub.cuda(), max_steps=steps, gate_threshold=2.0, prenet_dropout=False)
+    torch.cuda.synchronize()
+    assert n == steps and int(stop[0]) == -1
+    assert maxabs(dp.mel.cpu().transpose(1, 2), g["fixed_mel"]) < TOL
+    assert maxabs(dp.gate.cpu().unsqueeze(-1), g["fixed_gate"]) < TOL
+    assert maxabs(dp.align.cpu(), g["fixed_align"]) < TOL
+    assert maxabs(dp.align_sub.cpu(), g["fixed_align_bert"]) < TOL
+    # stop rule: index bit-exact
+    dp2, n2, stop2 = ops.decoder_infer(W, dims, mem.cuda(), mem_sub.cuda(), max_steps=1000,
+                                       gate_threshold=float(g["stop_threshold"]), prenet_dropout=False, poll_every=4)
+    torch.cuda.synchronize()
+    k = int(g["stop_index"])
+    assert int(stop2[0]) == k
+    assert k + 1 <= n2 <= k + 4
+    assert maxabs(dp2.mel[:, :k + 1].cpu().transpose(1, 2), g["stop_mel"]) < TOL
+
+
+def test_inference_batch_equals_single_items(env):
+    """B > 1 has no reference behaviour (model.py:461 breaks); the rule is: every item behaves
+    exactly like its own B == 1 run."""
+    L, ops = env
+    hp = tiny_hp(SMA)
+    P = recipe.make_weights(hp, seed=11)
+    B, Tin, Tsub, steps = 4, 9, 6, 12
+    b = recipe.make_batch(hp, B, Tin, Tsub, 8, seed=77, ragged=False)
+    with torch.no_grad():
+        mem = O.front_end(P, hp, b[0], None, b[7], "phone", False)
+        mem_sub = O.front_end(P, hp, b[6], None, b[8], "sub", False)
+    dims = L.dims_from_hparams(hp)
+    Pd = to_dev(P)
+    W = L.decoder_weights(Pd, dims.attention_kind)
+    dp, n, stop = ops.decoder_infer(W, dims, mem.cuda(), mem_sub.cuda(), max_steps=steps, gate_threshold=2.0, prenet_dropout=False)
+    torch.cuda.synchronize()
+    for i in range(B):
+        with torch.no_grad():
+            mel, gate, al, alb, flag = O.decoder_inference(mem[i:i + 1], mem_sub[i:i + 1], P, hp, max_decoder_steps=steps, gate_threshold=2.0)
+        assert maxabs(dp.mel[i:i + 1].cpu().transpose(1, 2), mel) < TOL
+        assert maxabs(dp.align[i:i + 1].cpu(), al) < TOL

@@ -1,0 +1,84 @@
+"""GPU parity tests of the individual HIP kernels (GEMM, RNG) through the C ABI."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from tacotron2_subword_amd import ops as _ops
+    return _ops
+
+
+def _ref(A, B, ta, tb):
+    a = A.double().cpu()
+    b = B.double().cpu()
+    a = a.t() if ta else a
+    b = b.t() if tb else b
+    return a @ b
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 1024), (200, 80, 2048), (37, 1, 2048), (256, 512, 80), (130, 257, 100),
+                                   (1, 4096, 768), (2560, 512, 400)])
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, True), (True, False)])
+def test_gemm_layouts(ops, M, N, K, ta, tb):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g).cuda()
+    B = torch.randn((N, K) if tb else (K, N), generator=g).cuda()
+    C = ops.gemm(A, B, trans_a=ta, trans_b=tb)
+    ref = _ref(A, B, ta, tb)
+    err = (C.double().cpu() - ref).abs().max().item()
+    assert err < 2e-4 * max(1.0, K ** 0.5 / 8), err      # fp32 fma chain vs fp64
+
+
+def test_gemm_epilogue_and_splitk(ops):
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(64, 4096, generator=g).cuda()
+    B = torch.randn(128, 4096, generator=g).cuda()
+    bias = torch.randn(128, generator=g).cuda()
+    C0 = torch.randn(64, 128, generator=g).cuda()
+    ref = torch.relu(0.5 * (A.double().cpu() @ B.double().cpu().t()) + bias.double().cpu())
+    out = ops.gemm(A, B, bias=bias, act=1, alpha=0.5)
+    assert (out.double().cpu() - ref).abs().max().item() < 5e-4
+    ws = torch.empty(8 * 64 * 128, device="cuda")
+    out2 = ops.gemm(A, B, bias=bias, act=1, alpha=0.5, ws=ws, splitk=8)
+    assert (out2.double().cpu() - ref).abs().max().item() < 5e-4
+    out3 = C0.clone()
+    ops.gemm(A, B, alpha=1.0, beta=2.0, out=out3)
+    ref3 = A.double().cpu() @ B.double().cpu().t() + 2.0 * C0.double().cpu()
+    assert (out3.double().cpu() - ref3).abs().max().item() < 1e-3
+    t = ops.gemm(A[:, :256].contiguous(), B[:, :256].contiguous(), act=2)
+    assert (t.double().cpu() - torch.tanh(A[:, :256].double().cpu() @ B[:, :256].double().cpu().t())).abs().max().item() < 1e-5
+
+
+def test_gemm_strided_rows(ops):
+    """Rows of A and C taken with a stride (the per-step views of [B,T,W] buffers)."""
+    g = torch.Generator().manual_seed(9)
+    big = torch.randn(8, 5, 192, generator=g).cuda()          # [B,T,W]
+    W = torch.randn(48, 192, generator=g).cuda()
+    out = torch.zeros(8, 5, 48).cuda()
+    A = big[:, 3, :]                                             # stride 5*192
+    Cv = out[:, 3, :]
+    from tacotron2_subword_amd import _lib as L
+    L.check(L.lib().t2_gemm(A.data_ptr(), W.data_ptr(), Cv.data_ptr(), 8, 48, 192, A.stride(0), 1, W.stride(0), 1,
+                            Cv.stride(0), None, 0, 1.0, 0.0, None, 0, 0, L.stream()))
+    ref = big[:, 3, :].double().cpu() @ W.double().cpu().t()
+    assert (out[:, 3].double().cpu() - ref).abs().max().item() < 1e-4
+    assert out[:, 2].abs().max().item() == 0.0
+
+
+def test_rng_statistics_and_determinism(ops):
+    n = 1 << 20
+    m1 = ops.rng_keep_mask(1234, 5, n, 0.1)
+    m2 = ops.rng_keep_mask(1234, 5, n, 0.1)
+    m3 = ops.rng_keep_mask(1234, 6, n, 0.1)
+    assert torch.equal(m1, m2)
+    assert not torch.equal(m1, m3)
+    assert abs(m1.float().mean().item() - 0.9) < 2e-3
+    assert abs(ops.rng_keep_mask(99, 1, n, 0.5).float().mean().item() - 0.5) < 3e-3
+    z = ops.rng_normal(7, 11, n)
+    assert abs(z.mean().item()) < 5e-3 and abs(z.std().item() - 1.0) < 5e-3
+    assert torch.isfinite(z).all()
+    zc = z.cpu()
+    assert abs(float((zc[:-1] * zc[1:]).mean())) < 5e-3       # neighbouring indices decorrelated
