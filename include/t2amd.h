@@ -86,6 +86,7 @@ typedef struct t2_decoder_layout {
     size_t wcum, wcums;               /* LSA cumulative weights per step [B,T,Tin], [B,T,Tsub] */
     size_t pred, gd, cnd, cd;         /* decoder LSTM: pre-activations, gates [B,T,4*Hd], cells [B,T,Hd] */
     size_t dout;                      /* [B,T, Hd+2*E] = dec_h | ctx | ctx_sub */
+    size_t qs, qss;                   /* processed query per step [B,T,A] */
     size_t qpart;                     /* per-step scratch [2][Ha/8][B][A] */
     size_t gemm_ws; size_t gemm_ws_floats;
 } t2_decoder_layout;
@@ -111,6 +112,42 @@ typedef struct t2_decoder_fwd_args {
     uint64_t seed;
 } t2_decoder_fwd_args;
 int t2_decoder_forward(const t2_dims* dims, const t2_decoder_weights* w, const t2_decoder_fwd_args* a, void* stream);
+
+/* Backward of t2_decoder_forward (the autograd graph PyTorch builds for Decoder.forward in the
+ * reference).  Gradients are written (not accumulated) into `g`, which has the shapes of the
+ * weights; d_memory / d_memory_sub receive the gradient wrt the encoder memories.
+ * SMA only in this version (T2_ATTN_LSA returns an error). */
+typedef struct t2_lstm_grads { float *w_ih, *w_hh, *b_ih, *b_hh; } t2_lstm_grads;
+typedef struct t2_attention_grads { float *wq, *wm, *v, *loc_conv, *loc_dense; } t2_attention_grads;
+typedef struct t2_decoder_grads {
+    float *prenet_w1, *prenet_w2, *prenet_sub_w1, *prenet_sub_w2;
+    t2_lstm_grads att, att_sub;
+    t2_attention_grads attn, attn_sub;
+    t2_lstm_grads dec;
+    float *proj_w, *proj_b, *gate_w, *gate_b;
+} t2_decoder_grads;
+typedef struct t2_decoder_bwd_layout {
+    size_t total_floats;
+    size_t ddout, ddin, dgd, dga, dgas, dctx, dctxs, dq, dqs, dv, dvs, dpm, dpms, carry, carrys;
+    size_t dcd, dca, dcas, partd, parta, dp2, dp2s, dp1, colsum_ws, gemm_ws, gemm_ws_floats;
+} t2_decoder_bwd_layout;
+int t2_decoder_bwd_layout_query(const t2_dims* dims, int B, int T, int Tin, int Tsub, t2_decoder_bwd_layout* out);
+typedef struct t2_decoder_bwd_args {
+    int B, T, Tin, Tsub;
+    const float* memory; const float* memory_sub;
+    const float* align; const float* align_sub;     /* forward outputs [B,T,Tin], [B,T,Tsub] */
+    const float* d_mel;        /* [B,T,n_mel] */
+    const float* d_gate;       /* [B,T] */
+    const float* d_align;      /* [B,T,Tin] or NULL */
+    const float* d_align_sub;  /* [B,T,Tsub] or NULL */
+    float* d_memory;           /* [B,Tin,E] out */
+    float* d_memory_sub;       /* [B,Tsub,E] out */
+    const float* ws;           /* workspace filled by t2_decoder_forward */
+    float* bws;                /* t2_decoder_bwd_layout.total_floats floats of scratch */
+    int training; int prenet_dropout; uint64_t seed;   /* must equal the forward call's */
+} t2_decoder_bwd_args;
+int t2_decoder_backward(const t2_dims* dims, const t2_decoder_weights* w, const t2_decoder_grads* g,
+                        const t2_decoder_bwd_args* a, void* stream);
 
 /* Autoregressive decode — replaces Decoder.inference (model.py:430-492) for any B.
  * Per-item stop rule: stop_index[b] = first t with sigmoid(gate) > threshold.

@@ -46,7 +46,7 @@ class DecoderWeights(C.Structure):
 
 _LAYOUT_FIELDS = ["total_floats", "x", "p1", "p2", "p1s", "p2s", "pm", "pms", "prea", "preas", "ga", "gas",
                   "cna", "cnas", "ca", "cas", "din", "psel", "psels", "wcum", "wcums", "pred", "gd", "cnd", "cd",
-                  "dout", "qpart", "gemm_ws", "gemm_ws_floats"]
+                  "dout", "qs", "qss", "qpart", "gemm_ws", "gemm_ws_floats"]
 
 
 class DecoderLayout(C.Structure):
@@ -70,8 +70,40 @@ class DecoderInferArgs(C.Structure):
                 ("prenet_dropout", C.c_int), ("seed", C.c_uint64), ("steps_run_host", C.POINTER(C.c_int))]
 
 
+class LstmGrads(C.Structure):
+    _fields_ = LstmWeights._fields_
+
+
+class AttentionGrads(C.Structure):
+    _fields_ = AttentionWeights._fields_
+
+
+class DecoderGrads(C.Structure):
+    _fields_ = [("prenet_w1", C.c_void_p), ("prenet_w2", C.c_void_p), ("prenet_sub_w1", C.c_void_p), ("prenet_sub_w2", C.c_void_p),
+                ("att", LstmGrads), ("att_sub", LstmGrads), ("attn", AttentionGrads), ("attn_sub", AttentionGrads),
+                ("dec", LstmGrads), ("proj_w", C.c_void_p), ("proj_b", C.c_void_p), ("gate_w", C.c_void_p), ("gate_b", C.c_void_p)]
+
+
+_BWD_LAYOUT_FIELDS = ["total_floats", "ddout", "ddin", "dgd", "dga", "dgas", "dctx", "dctxs", "dq", "dqs", "dv", "dvs",
+                      "dpm", "dpms", "carry", "carrys", "dcd", "dca", "dcas", "partd", "parta", "dp2", "dp2s", "dp1",
+                      "colsum_ws", "gemm_ws", "gemm_ws_floats"]
+
+
+class DecoderBwdLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in _BWD_LAYOUT_FIELDS]
+
+
+class DecoderBwdArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("Tin", C.c_int), ("Tsub", C.c_int),
+                ("memory", C.c_void_p), ("memory_sub", C.c_void_p), ("align", C.c_void_p), ("align_sub", C.c_void_p),
+                ("d_mel", C.c_void_p), ("d_gate", C.c_void_p), ("d_align", C.c_void_p), ("d_align_sub", C.c_void_p),
+                ("d_memory", C.c_void_p), ("d_memory_sub", C.c_void_p), ("ws", C.c_void_p), ("bws", C.c_void_p),
+                ("training", C.c_int), ("prenet_dropout", C.c_int), ("seed", C.c_uint64)]
+
+
 # every symbol include/t2amd.h declares (tests/test_abi.py checks the library exports them all)
 EXPORTS = ["t2_last_error", "t2_version", "t2_decoder_layout_query", "t2_decoder_forward", "t2_decoder_infer",
+           "t2_decoder_bwd_layout_query", "t2_decoder_backward",
            "t2_finalize_bct", "t2_mask_bt", "t2_gemm", "t2_rng_keep_mask", "t2_rng_normal"]
 
 _lib = None
@@ -93,6 +125,9 @@ def lib() -> C.CDLL:
         L.t2_decoder_layout_query.argtypes = [C.POINTER(Dims), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(DecoderLayout)]
         L.t2_decoder_forward.argtypes = [C.POINTER(Dims), C.POINTER(DecoderWeights), C.POINTER(DecoderFwdArgs), C.c_void_p]
         L.t2_decoder_infer.argtypes = [C.POINTER(Dims), C.POINTER(DecoderWeights), C.POINTER(DecoderInferArgs), C.c_void_p]
+        L.t2_decoder_bwd_layout_query.argtypes = [C.POINTER(Dims), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(DecoderBwdLayout)]
+        L.t2_decoder_backward.argtypes = [C.POINTER(Dims), C.POINTER(DecoderWeights), C.POINTER(DecoderGrads),
+                                          C.POINTER(DecoderBwdArgs), C.c_void_p]
         L.t2_finalize_bct.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p]
         L.t2_mask_bt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p]
         _lib = L
@@ -145,6 +180,38 @@ def decoder_weights(P: dict, kind: int, prefix: str = "decoder.") -> DecoderWeig
                           lstm("attention_rnn"), lstm("attention_rnn_bert"), attn("attention_layer"), attn("attention_layer_bert"),
                           lstm("decoder_rnn"), p("linear_projection.linear_layer.weight"), p("linear_projection.linear_layer.bias"),
                           p("gate_layer.linear_layer.weight"), p("gate_layer.linear_layer.bias"))
+
+
+DECODER_PARAM_KEYS_SMA = [
+    "prenet.layers.0.linear_layer.weight", "prenet.layers.1.linear_layer.weight",
+    "prenet_bert.layers.0.linear_layer.weight", "prenet_bert.layers.1.linear_layer.weight",
+    "attention_rnn.weight_ih", "attention_rnn.weight_hh", "attention_rnn.bias_ih", "attention_rnn.bias_hh",
+    "attention_rnn_bert.weight_ih", "attention_rnn_bert.weight_hh", "attention_rnn_bert.bias_ih", "attention_rnn_bert.bias_hh",
+    "attention_layer.query_layer.linear_layer.weight", "attention_layer.memory_layer.linear_layer.weight", "attention_layer.v.weight",
+    "attention_layer_bert.query_layer.linear_layer.weight", "attention_layer_bert.memory_layer.linear_layer.weight",
+    "attention_layer_bert.v.weight",
+    "decoder_rnn.weight_ih", "decoder_rnn.weight_hh", "decoder_rnn.bias_ih", "decoder_rnn.bias_hh",
+    "linear_projection.linear_layer.weight", "linear_projection.linear_layer.bias",
+    "gate_layer.linear_layer.weight", "gate_layer.linear_layer.bias"]
+
+
+def decoder_grads(G: dict, prefix: str = "decoder.") -> DecoderGrads:
+    """Pack pointers of gradient buffers keyed like the weights (SMA parameter set)."""
+    p = lambda k: ptr(G[prefix + k])
+    lstm = lambda n: LstmGrads(p(n + ".weight_ih"), p(n + ".weight_hh"), p(n + ".bias_ih"), p(n + ".bias_hh"))
+    attn = lambda n: AttentionGrads(p(n + ".query_layer.linear_layer.weight"), p(n + ".memory_layer.linear_layer.weight"),
+                                    p(n + ".v.weight"), None, None)
+    return DecoderGrads(p("prenet.layers.0.linear_layer.weight"), p("prenet.layers.1.linear_layer.weight"),
+                        p("prenet_bert.layers.0.linear_layer.weight"), p("prenet_bert.layers.1.linear_layer.weight"),
+                        lstm("attention_rnn"), lstm("attention_rnn_bert"), attn("attention_layer"), attn("attention_layer_bert"),
+                        lstm("decoder_rnn"), p("linear_projection.linear_layer.weight"), p("linear_projection.linear_layer.bias"),
+                        p("gate_layer.linear_layer.weight"), p("gate_layer.linear_layer.bias"))
+
+
+def decoder_bwd_layout(dims: Dims, B: int, T: int, Tin: int, Tsub: int) -> DecoderBwdLayout:
+    L = DecoderBwdLayout()
+    check(lib().t2_decoder_bwd_layout_query(C.byref(dims), B, T, Tin, Tsub, C.byref(L)))
+    return L
 
 
 def decoder_layout(dims: Dims, B: int, T: int, Tin: int, Tsub: int) -> DecoderLayout:

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
             float sum = 0.f;
             for (int h2 = 0; h2 < nq; ++h2) sum += red[h2 * A + tid];
             q[tid] = sum;
+            if (st.q_out) st.q_out[(long)b * st.ldq_out + tid] = sum;
         }
     } else {
         for (int a = tid; a < A; a += NT) q[a] = st.query[(long)b * st.ldq + a];
@@ -201,6 +202,128 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Backward of one StepwiseMonotonicAttention step (reverse time), one workgroup per (b, stream).
+//   dctx   = direct sources + recurrent partials                      (saved: feeds d(memory) GEMM)
+//   g_j    = dctx . memory_j + dalign_j + carry_j                     total gradient on a_t[j]
+//   dp_j   = a_{t-1}[j] (g_j - g_{j+1}) ;  de_j = dp_j p_j (1 - p_j)
+//   u_jk   = tanh(q_k + pm_jk) ;  dpre_jk = de_j v_k (1 - u_jk^2)
+//   dq_k   = sum_j dpre_jk ; dv_k += sum_j de_j u_jk ; dpm_jk += dpre_jk
+//   carry_j <- g_j p_j + g_{j+1} (1 - p_j)                            gradient on a_{t-1}[j]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void attention_step_bwd_kernel(AttnBwdDesc d) {
+    const AttnBwdStream& st = d.st[blockIdx.y];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int Tin = st.Tin, A = d.A, E = d.E;
+    const int Tp = (Tin + 3) & ~3;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dctx = smem;              // [E]
+    float* q = dctx + E;             // [A]
+    float* vs = q + A;               // [A]
+    float* g = vs + A;               // [Tp + 1]  (g[Tin] = 0)
+    float* de = g + Tp + 4;          // [Tp]
+    float* ps = de + Tp;             // [Tp]
+    float* red = ps + Tp;            // [16][A] x 2 (dq, dv partials of the 16 position groups)
+
+    for (int c = tid; c < E; c += NT) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) if (st.dctx[i]) v += st.dctx[i][(long)b * st.lddctx[i] + c];
+        if (st.part && !d.first) {
+            const float* p = st.part + (long)b * st.ldpart + st.part_col + c;
+            float acc = 0.f;
+            for (int z = 0; z < st.nparts; ++z) acc += p[(long)z * st.part_stride];
+            v += acc;
+        }
+        dctx[c] = v;
+        st.dctx_out[(long)b * st.lddctx_out + c] = v;
+    }
+    for (int a = tid; a < A; a += NT) { q[a] = st.q[(long)b * st.ldq + a]; vs[a] = st.v[a]; }
+    for (int j = tid; j < Tin; j += NT) ps[j] = st.p[(long)b * st.ldp + j];
+    if (tid == 0) g[Tin] = 0.f;
+    __syncthreads();
+
+    // g_j: one wave per position, lanes stride the E channels 16 B at a time
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int j = wave; j < Tin; j += NT / 64) {
+            const float* mr = st.memory + ((long)b * Tin + j) * E;
+            float sum = 0.f;
+            for (int c = lane * 4; c < E; c += 256) {
+                const f32x4 mv = *reinterpret_cast<const f32x4*>(mr + c);
+                sum += mv[0] * dctx[c] + mv[1] * dctx[c + 1] + mv[2] * dctx[c + 2] + mv[3] * dctx[c + 3];
+            }
+            sum = wave_sum(sum);
+            if (lane == 0) {
+                if (st.dalign) sum += st.dalign[(long)b * st.lddalign + j];
+                if (!d.first) sum += st.carry[(long)b * Tin + j];
+                g[j] = sum;
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < Tin; j += NT) {
+        const float ap = st.a_prev ? st.a_prev[(long)b * st.lda_prev + j] : (j == 0 ? 1.f : 0.f);
+        const float p = ps[j];
+        const float gj = g[j], gn = g[j + 1];
+        de[j] = ap * (gj - gn) * p * (1.0f - p);
+        st.carry[(long)b * Tin + j] = gj * p + gn * (1.0f - p);
+    }
+    __syncthreads();
+
+    // energies backward: 16 lanes per position, each lane owns channels sub*4 + 64*i
+    {
+        const int gid = tid >> 4, sub = tid & 15;
+        constexpr int MAXI = 4;                                   // A <= 256
+        float dq[MAXI][4], dv[MAXI][4];
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { dq[i][c] = 0.f; dv[i][c] = 0.f; }
+        for (int j = gid; j < Tin; j += NT / 16) {
+            const float dej = de[j];
+            const float* pmr = st.pm + ((long)b * Tin + j) * A;
+            float* dpr = st.dpm_acc + ((long)b * Tin + j) * A;
+#pragma unroll
+            for (int i = 0; i < MAXI; ++i) {
+                const int a = sub * 4 + 64 * i;
+                if (a < A) {
+                    const f32x4 pv = *reinterpret_cast<const f32x4*>(pmr + a);
+                    f32x4 acc = d.first ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(dpr + a);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float u = tanhf(q[a + c] + pv[c]);
+                        const float dpre = dej * vs[a + c] * (1.0f - u * u);
+                        dq[i][c] += dpre;
+                        dv[i][c] += dej * u;
+                        acc[c] += dpre;
+                    }
+                    *reinterpret_cast<f32x4*>(dpr + a) = acc;
+                }
+            }
+        }
+        float* rq = red;
+        float* rv = red + 16 * A;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int a = sub * 4 + 64 * i;
+            if (a < A) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { rq[gid * A + a + c] = dq[i][c]; rv[gid * A + a + c] = dv[i][c]; }
+            }
+        }
+        __syncthreads();
+        for (int a = tid; a < A; a += NT) {
+            float sq = 0.f, sv = 0.f;
+            for (int k = 0; k < 16; ++k) { sq += rq[k * A + a]; sv += rv[k * A + a]; }
+            st.dq_out[(long)b * st.lddq_out + a] = sq;
+            float* dvp = st.dv_acc + (long)b * A + a;
+            *dvp = (d.first ? 0.f : *dvp) + sv;
+        }
+    }
+}
+
 }  // namespace
 
 size_t attention_fwd_smem(const AttnStepDesc& d) {
@@ -227,6 +350,24 @@ int attention_step_fwd(const AttnStepDesc& d, hipStream_t s) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     }
     hipLaunchKernelGGL(attention_step_fwd_kernel, dim3(d.B, d.nstreams), dim3(NT), smem, s, d);
+    T2_LAUNCH_CHECK();
+    return 0;
+}
+
+
+int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s) {
+    T2_REQUIRE(d.nstreams >= 1 && d.nstreams <= 2, "attention_bwd: nstreams=%d", d.nstreams);
+    T2_REQUIRE(d.A % 4 == 0 && d.A <= 256 && d.E % 4 == 0, "attention_bwd: A=%d E=%d unsupported", d.A, d.E);
+    int Tmax = 0;
+    for (int i = 0; i < d.nstreams; ++i) Tmax = d.st[i].Tin > Tmax ? d.st[i].Tin : Tmax;
+    const int Tp = (Tmax + 3) & ~3;
+    const size_t smem = ((size_t)d.E + 2 * d.A + (Tp + 4) + 2 * Tp + 32 * (size_t)d.A) * sizeof(float);
+    T2_REQUIRE(smem <= 160 * 1024, "attention_bwd: T_in too long for LDS (%zu bytes)", smem);
+    if (smem > 64 * 1024) {
+        T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_step_bwd_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    }
+    hipLaunchKernelGGL(attention_step_bwd_kernel, dim3(d.B, d.nstreams), dim3(NT), smem, s, d);
     T2_LAUNCH_CHECK();
     return 0;
 }

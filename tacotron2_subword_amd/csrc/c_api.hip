@@ -66,6 +66,7 @@ void layout_of(const t2_dims& d, const Sizes& z, t2_decoder_layout* L) {
     L->pred = take(BT * 4 * z.Hd); L->gd = take(BT * 4 * z.Hd);
     L->cnd = take(BT * z.Hd); L->cd = take(BT * z.Hd);
     L->dout = take(BT * z.WO);
+    L->qs = take(BT * z.A); L->qss = take(BT * z.A);
     L->qpart = take((size_t)2 * (z.Ha / 8) * z.B * z.A);
     L->gemm_ws_floats = (size_t)16 << 20;                     // 64 MiB of split-K scratch
     L->gemm_ws = take(L->gemm_ws_floats);
@@ -159,6 +160,7 @@ int attention_step(const Dec& c, int t) {
         const long ldA = (long)z.T * Tin;
         st.Tin = Tin;
         st.qpart = c.P(L.qpart) + (size_t)s * (z.Ha / 8) * z.B * z.A; st.nparts = z.Ha / 8;
+        st.q_out = c.P(s ? L.qss : L.qs) + (long)t * z.A; st.ldq_out = (long)z.T * z.A;
         st.pm = c.P(s ? L.pms : L.pm); st.memory = s ? c.memory_sub : c.memory;
         st.lengths = s ? c.len_sub : c.len;
         st.a_prev = t > 0 ? al + (long)(t - 1) * Tin : nullptr; st.lda_prev = ldA;
@@ -239,6 +241,149 @@ __global__ void init_stop_kernel(int32_t* stop_index, int32_t* done, int B) {
     if (b == 0) *done = 0;
 }
 
+
+// ------------------------------------------------------------------------------- backward
+void bwd_layout_of(const t2_dims& d, const Sizes& z, t2_decoder_bwd_layout* L) {
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += align4(n); return o; };
+    const size_t BT = (size_t)z.B * z.T;
+    const int ksd = lstm_bwd_ksplit(4 * z.Hd), ksa = lstm_bwd_ksplit(4 * z.Ha);
+    L->ddout = take(BT * z.WO); L->ddin = take(BT * z.WD);
+    L->dgd = take(BT * 4 * z.Hd); L->dga = take(BT * 4 * z.Ha); L->dgas = take(BT * 4 * z.Ha);
+    L->dctx = take(BT * z.E); L->dctxs = take(BT * z.E);
+    L->dq = take(BT * z.A); L->dqs = take(BT * z.A);
+    L->dv = take((size_t)z.B * z.A); L->dvs = take((size_t)z.B * z.A);
+    L->dpm = take((size_t)z.B * z.Tin * z.A); L->dpms = take((size_t)z.B * z.Tsub * z.A);
+    L->carry = take((size_t)z.B * z.Tin); L->carrys = take((size_t)z.B * z.Tsub);
+    L->dcd = take((size_t)z.B * z.Hd); L->dca = take((size_t)z.B * z.Ha); L->dcas = take((size_t)z.B * z.Ha);
+    L->partd = take((size_t)ksd * z.B * z.Hd);
+    L->parta = take((size_t)2 * ksa * z.B * (z.E + z.Ha));
+    L->dp2 = take(BT * z.P); L->dp2s = take(BT * z.P); L->dp1 = take(BT * z.P);
+    L->colsum_ws = take((size_t)64 * 4 * (z.Ha > z.Hd ? z.Ha : z.Hd));
+    L->gemm_ws_floats = (size_t)48 << 20;                     // 192 MiB of split-K scratch
+    L->gemm_ws = take(L->gemm_ws_floats);
+    L->total_floats = off;
+}
+
+struct Bwd {
+    const t2_dims& d; const t2_decoder_weights& w; const t2_decoder_grads& g; const t2_decoder_bwd_args& a;
+    Sizes z; t2_decoder_layout L; t2_decoder_bwd_layout BL; hipStream_t s;
+    const float* W(size_t off) const { return a.ws + off; }
+    float* S(size_t off) const { return a.bws + off; }
+    float* gemm_ws() const { return a.bws + BL.gemm_ws; }
+    size_t gemm_ws_bytes() const { return BL.gemm_ws_floats * sizeof(float); }
+};
+
+// C[M,N] = X[M,K] . W[K,N]   (W row-major with leading dimension ldw: "NN")
+GemmDesc matmul_nn(const float* X, long ldx, const float* W, long ldw, float* Y, long ldy, int M, int N, int K) {
+    GemmDesc g = gemm_desc();
+    g.A = X; g.sam = ldx; g.sak = 1;
+    g.B = W; g.sbk = ldw; g.sbn = 1;
+    g.C = Y; g.ldc = ldy; g.M = M; g.N = N; g.K = K;
+    return g;
+}
+// C[M,N] = G[K,M]^T . X[K,N]   (weight gradients: K = B*T rows)
+GemmDesc matmul_tn(const Bwd& c, const float* G, long ldg, const float* X, long ldx, float* Y, long ldy, int M, int N, int K) {
+    GemmDesc g = gemm_desc();
+    g.A = G; g.sam = 1; g.sak = ldg;
+    g.B = X; g.sbk = ldx; g.sbn = 1;
+    g.C = Y; g.ldc = ldy; g.M = M; g.N = N; g.K = K;
+    g.ws = c.gemm_ws(); g.ws_bytes = c.gemm_ws_bytes();
+    return g;
+}
+
+int dec_bwd_step(const Bwd& c, int t) {
+    const Sizes& z = c.z;
+    const int ks = lstm_bwd_ksplit(4 * z.Hd);
+    LstmBwdPointDesc p{};
+    p.nstreams = 1; p.B = z.B; p.H = z.Hd; p.seed = c.a.seed; p.first = t == z.T - 1;
+    p.drop_p = c.a.training ? c.d.p_dec_dropout : 0.f;
+    LstmBwdStream& st = p.st[0];
+    st.dh1 = c.S(c.BL.ddout) + (long)t * z.WO; st.lddh1 = (long)z.T * z.WO;
+    st.part = c.S(c.BL.partd); st.nparts = ks; st.part_stride = (long)z.B * z.Hd; st.ldpart = z.Hd; st.part_col = 0;
+    st.gates = c.W(c.L.gd) + (long)t * 4 * z.Hd; st.ldgates = (long)z.T * 4 * z.Hd;
+    st.c_new = c.W(c.L.cnd) + (long)t * z.Hd; st.ldc_new = (long)z.T * z.Hd;
+    if (t > 0) { st.c_prev = c.W(c.L.cd) + (long)(t - 1) * z.Hd; st.ldc_prev = (long)z.T * z.Hd; }
+    st.dc_state = c.S(c.BL.dcd);
+    st.dg = c.S(c.BL.dgd) + (long)t * 4 * z.Hd; st.lddg = (long)z.T * 4 * z.Hd;
+    st.site_h = T2_SITE_DEC_H; st.site_c = T2_SITE_DEC_C;
+    st.idx_base = (uint32_t)t * z.Hd; st.idx_bstride = (uint32_t)z.T * z.Hd;
+    T2_TRY(lstm_bwd_pointwise(p, c.s));
+    if (t == 0) return 0;
+    LstmBwdGemmDesc g{};
+    g.nstreams = 1; g.B = z.B; g.H4 = 4 * z.Hd; g.KS = ks; g.NC = z.Hd;
+    g.st[0].dg = st.dg; g.st[0].lddg = st.lddg;
+    g.st[0].seg[0] = LstmBwdSeg{c.w.dec.w_hh, (long)z.Hd, z.Hd}; g.st[0].nseg = 1;
+    g.st[0].part = c.S(c.BL.partd);
+    return lstm_bwd_gemm(g, c.s);
+}
+
+int att_bwd_step(const Bwd& c, int t) {
+    const Sizes& z = c.z;
+    const int ks = lstm_bwd_ksplit(4 * z.Ha);
+    const int NC = z.E + z.Ha;
+    const bool first = t == z.T - 1;
+    // 1. attention backward (needs dctx(t) incl. the recurrent partials of step t+1)
+    AttnBwdDesc ab{};
+    ab.nstreams = 2; ab.B = z.B; ab.A = z.A; ab.E = z.E; ab.first = first;
+    for (int s = 0; s < 2; ++s) {
+        AttnBwdStream& st = ab.st[s];
+        const int Tin = s ? z.Tsub : z.Tin;
+        const int hoff = s ? z.Ha + z.E : 0, coff = hoff + z.Ha;
+        st.Tin = Tin;
+        st.dctx[0] = c.S(c.BL.ddout) + (long)t * z.WO + z.Hd + (s ? z.E : 0); st.lddctx[0] = (long)z.T * z.WO;
+        st.dctx[1] = c.S(c.BL.ddin) + (long)t * z.WD + coff; st.lddctx[1] = (long)z.T * z.WD;
+        st.part = c.S(c.BL.parta) + (size_t)s * ks * z.B * NC; st.nparts = ks; st.part_stride = (long)z.B * NC; st.ldpart = NC; st.part_col = 0;
+        const float* dal = s ? c.a.d_align_sub : c.a.d_align;
+        if (dal) { st.dalign = dal + (long)t * Tin; st.lddalign = (long)z.T * Tin; }
+        st.q = c.W(s ? c.L.qss : c.L.qs) + (long)t * z.A; st.ldq = (long)z.T * z.A;
+        st.pm = c.W(s ? c.L.pms : c.L.pm); st.memory = s ? c.a.memory_sub : c.a.memory;
+        st.p = c.W(s ? c.L.psels : c.L.psel) + (long)t * Tin; st.ldp = (long)z.T * Tin;
+        const float* al = s ? c.a.align_sub : c.a.align;
+        if (t > 0) { st.a_prev = al + (long)(t - 1) * Tin; st.lda_prev = (long)z.T * Tin; }
+        st.v = s ? c.w.attn_sub.v : c.w.attn.v;
+        st.carry = c.S(s ? c.BL.carrys : c.BL.carry);
+        st.dctx_out = c.S(s ? c.BL.dctxs : c.BL.dctx) + (long)t * z.E; st.lddctx_out = (long)z.T * z.E;
+        st.dq_out = c.S(s ? c.BL.dqs : c.BL.dq) + (long)t * z.A; st.lddq_out = (long)z.T * z.A;
+        st.dv_acc = c.S(s ? c.BL.dvs : c.BL.dv);
+        st.dpm_acc = c.S(s ? c.BL.dpms : c.BL.dpm);
+    }
+    T2_TRY(attention_step_bwd(ab, c.s));
+    // 2. LSTM pointwise backward
+    LstmBwdPointDesc p{};
+    p.nstreams = 2; p.B = z.B; p.H = z.Ha; p.seed = c.a.seed; p.first = first;
+    p.drop_p = c.a.training ? c.d.p_att_dropout : 0.f;
+    for (int s = 0; s < 2; ++s) {
+        LstmBwdStream& st = p.st[s];
+        const int hoff = s ? z.Ha + z.E : 0;
+        st.dh1 = c.S(c.BL.ddin) + (long)t * z.WD + hoff; st.lddh1 = (long)z.T * z.WD;
+        st.part = c.S(c.BL.parta) + (size_t)s * ks * z.B * NC; st.nparts = ks; st.part_stride = (long)z.B * NC; st.ldpart = NC; st.part_col = z.E;
+        st.dq = c.S(s ? c.BL.dqs : c.BL.dq) + (long)t * z.A; st.lddq = (long)z.T * z.A;
+        st.wq = s ? c.w.attn_sub.wq : c.w.attn.wq; st.A = z.A;
+        st.gates = c.W(s ? c.L.gas : c.L.ga) + (long)t * 4 * z.Ha; st.ldgates = (long)z.T * 4 * z.Ha;
+        st.c_new = c.W(s ? c.L.cnas : c.L.cna) + (long)t * z.Ha; st.ldc_new = (long)z.T * z.Ha;
+        if (t > 0) { st.c_prev = c.W(s ? c.L.cas : c.L.ca) + (long)(t - 1) * z.Ha; st.ldc_prev = (long)z.T * z.Ha; }
+        st.dc_state = c.S(s ? c.BL.dcas : c.BL.dca);
+        st.dg = c.S(s ? c.BL.dgas : c.BL.dga) + (long)t * 4 * z.Ha; st.lddg = (long)z.T * 4 * z.Ha;
+        st.site_h = s ? T2_SITE_ATT_H_SUB : T2_SITE_ATT_H; st.site_c = s ? T2_SITE_ATT_C_SUB : T2_SITE_ATT_C;
+        st.idx_base = (uint32_t)t * z.Ha; st.idx_bstride = (uint32_t)z.T * z.Ha;
+    }
+    T2_TRY(lstm_bwd_pointwise(p, c.s));
+    if (t == 0) return 0;
+    // 3. recurrent-input gradients of this step: dg(t) . [W_ih[:, P:] | W_hh]  ->  partials for step t-1
+    LstmBwdGemmDesc g{};
+    g.nstreams = 2; g.B = z.B; g.H4 = 4 * z.Ha; g.KS = ks; g.NC = NC;
+    for (int s = 0; s < 2; ++s) {
+        const t2_lstm_weights& lw = s ? c.w.att_sub : c.w.att;
+        g.st[s].dg = p.st[s].dg; g.st[s].lddg = p.st[s].lddg;
+        g.st[s].seg[0] = LstmBwdSeg{lw.w_ih + z.P, (long)(z.P + z.E), z.E};
+        g.st[s].seg[1] = LstmBwdSeg{lw.w_hh, (long)z.Ha, z.Ha};
+        g.st[s].nseg = 2;
+        g.st[s].part = c.S(c.BL.parta) + (size_t)s * ks * z.B * NC;
+    }
+    return lstm_bwd_gemm(g, c.s);
+}
+
 }  // namespace
 
 extern "C" {
@@ -294,6 +439,101 @@ int t2_decoder_forward(const t2_dims* dims, const t2_decoder_weights* w, const t
     for (int t = 0; t < z.T; ++t) T2_TRY(dec_lstm_step(c, t));
     // projections over all frames
     return projection(c, c.P(L.dout), z.WO, BT, a->mel_out, z.M, a->gate_out, 1);
+}
+
+
+int t2_decoder_bwd_layout_query(const t2_dims* dims, int B, int T, int Tin, int Tsub, t2_decoder_bwd_layout* out) {
+    T2_REQUIRE(dims && out, "null argument");
+    T2_TRY(check_dims(*dims));
+    T2_REQUIRE(B >= 1 && B <= 256 && T >= 1 && Tin >= 1 && Tsub >= 1, "bad shape B=%d T=%d Tin=%d Tsub=%d", B, T, Tin, Tsub);
+    bwd_layout_of(*dims, sizes_of(*dims, B, T, Tin, Tsub), out);
+    return 0;
+}
+
+int t2_decoder_backward(const t2_dims* dims, const t2_decoder_weights* w, const t2_decoder_grads* g,
+                        const t2_decoder_bwd_args* a, void* stream) {
+    T2_REQUIRE(dims && w && g && a, "null argument");
+    T2_TRY(check_dims(*dims));
+    T2_REQUIRE(dims->attention_kind == T2_ATTN_SMA, "t2_decoder_backward: only StepwiseMonotonicAttention has a backward kernel in this version");
+    Bwd c{*dims, *w, *g, *a, sizes_of(*dims, a->B, a->T, a->Tin, a->Tsub), {}, {}, (hipStream_t)stream};
+    layout_of(*dims, c.z, &c.L);
+    bwd_layout_of(*dims, c.z, &c.BL);
+    const Sizes& z = c.z; const t2_decoder_layout& L = c.L; const t2_decoder_bwd_layout& BL = c.BL;
+    const int BT = z.B * z.T;
+    float* cws = c.S(BL.colsum_ws);
+
+    // ---- projections (model.py:382-388): dDOUT = d_mel . Wproj + d_gate . Wgate ; weight gradients
+    {
+        GemmDesc x = matmul_nn(a->d_mel, z.M, w->proj_w, z.WO, c.S(BL.ddout), z.WO, BT, z.WO, z.M);
+        T2_TRY(gemm(x, c.s));
+        GemmDesc y = matmul_nn(a->d_gate, 1, w->gate_w, z.WO, c.S(BL.ddout), z.WO, BT, z.WO, 1);
+        y.beta = 1.f;
+        T2_TRY(gemm(y, c.s));
+        T2_TRY(gemm(matmul_tn(c, a->d_mel, z.M, c.W(L.dout), z.WO, g->proj_w, z.WO, z.M, z.WO, BT), c.s));
+        T2_TRY(gemm(matmul_tn(c, a->d_gate, 1, c.W(L.dout), z.WO, g->gate_w, z.WO, 1, z.WO, BT), c.s));
+        T2_TRY(colsum(a->d_mel, z.M, BT, z.M, g->proj_b, nullptr, cws, c.s));
+        T2_TRY(colsum(a->d_gate, 1, BT, 1, g->gate_b, nullptr, cws, c.s));
+    }
+    // ---- decoder LSTM, reverse time
+    for (int t = z.T - 1; t >= 0; --t) T2_TRY(dec_bwd_step(c, t));
+    {
+        const float* DG = c.S(BL.dgd);
+        // input half: dDIN = dG . W_ih ; dW_ih = dG^T . DIN ; recurrent half: dW_hh = dG^T . dec_h(t-1)
+        T2_TRY(gemm(matmul_nn(DG, 4 * z.Hd, w->dec.w_ih, z.WD, c.S(BL.ddin), z.WD, BT, z.WD, 4 * z.Hd), c.s));
+        T2_TRY(gemm(matmul_tn(c, DG, 4 * z.Hd, c.W(L.din), z.WD, g->dec.w_ih, z.WD, 4 * z.Hd, z.WD, BT), c.s));
+        GemmDesc hh = matmul_tn(c, DG, 4 * z.Hd, c.W(L.dout) - z.WO, z.WO, g->dec.w_hh, z.Hd, 4 * z.Hd, z.Hd, BT);
+        hh.kmask_period = z.T; hh.kmask_phase = 0;
+        T2_TRY(gemm(hh, c.s));
+        T2_TRY(colsum(DG, 4 * z.Hd, BT, 4 * z.Hd, g->dec.b_ih, g->dec.b_hh, cws, c.s));
+    }
+    // ---- attention LSTMs + attention, reverse time
+    for (int t = z.T - 1; t >= 0; --t) T2_TRY(att_bwd_step(c, t));
+    for (int s = 0; s < 2; ++s) {
+        const t2_lstm_weights& lw = s ? w->att_sub : w->att;
+        const t2_lstm_grads& lg = s ? g->att_sub : g->att;
+        const t2_attention_weights& aw = s ? w->attn_sub : w->attn;
+        const t2_attention_grads& ag = s ? g->attn_sub : g->attn;
+        const int hoff = s ? z.Ha + z.E : 0, coff = hoff + z.Ha;
+        const int Tin = s ? z.Tsub : z.Tin;
+        const float* DG = c.S(s ? BL.dgas : BL.dga);
+        const float* DIN = c.W(L.din);
+        const float* P1 = c.W(s ? L.p1s : L.p1); const float* P2 = c.W(s ? L.p2s : L.p2);
+        float* dP2 = c.S(s ? BL.dp2s : BL.dp2); float* dP1 = c.S(BL.dp1);
+        const long ldw = z.P + z.E;
+        // LSTM weights: W_ih = [prenet part | ctx part], W_hh, biases
+        T2_TRY(gemm(matmul_tn(c, DG, 4 * z.Ha, P2, z.P, lg.w_ih, ldw, 4 * z.Ha, z.P, BT), c.s));
+        GemmDesc wc = matmul_tn(c, DG, 4 * z.Ha, DIN - z.WD + coff, z.WD, lg.w_ih + z.P, ldw, 4 * z.Ha, z.E, BT);
+        wc.kmask_period = z.T; wc.kmask_phase = 0;
+        T2_TRY(gemm(wc, c.s));
+        GemmDesc wh = matmul_tn(c, DG, 4 * z.Ha, DIN - z.WD + hoff, z.WD, lg.w_hh, z.Ha, 4 * z.Ha, z.Ha, BT);
+        wh.kmask_period = z.T; wh.kmask_phase = 0;
+        T2_TRY(gemm(wh, c.s));
+        T2_TRY(colsum(DG, 4 * z.Ha, BT, 4 * z.Ha, lg.b_ih, lg.b_hh, cws, c.s));
+        // prenet (model.py:13-24): dP2 = dG . W_ih[:, :P] ; through ReLU+dropout ; layer 2 ; layer 1
+        const float scale = a->prenet_dropout ? 1.0f / (1.0f - dims->p_prenet_dropout) : 1.0f;
+        T2_TRY(gemm(matmul_nn(DG, 4 * z.Ha, lw.w_ih, ldw, dP2, z.P, BT, z.P, 4 * z.Ha), c.s));
+        T2_TRY(relu_drop_bwd(dP2, P2, dP2, scale, (size_t)BT * z.P, c.s));
+        T2_TRY(gemm(matmul_tn(c, dP2, z.P, P1, z.P, s ? g->prenet_sub_w2 : g->prenet_w2, z.P, z.P, z.P, BT), c.s));
+        T2_TRY(gemm(matmul_nn(dP2, z.P, s ? w->prenet_sub_w2 : w->prenet_w2, z.P, dP1, z.P, BT, z.P, z.P), c.s));
+        T2_TRY(relu_drop_bwd(dP1, P1, dP1, scale, (size_t)BT * z.P, c.s));
+        T2_TRY(gemm(matmul_tn(c, dP1, z.P, c.W(L.x), z.M, s ? g->prenet_sub_w1 : g->prenet_w1, z.M, z.P, z.M, BT), c.s));
+        // attention parameters
+        T2_TRY(gemm(matmul_tn(c, c.S(s ? BL.dqs : BL.dq), z.A, DIN + hoff, z.WD, ag.wq, z.Ha, z.A, z.Ha, BT), c.s));
+        T2_TRY(batch_sum(c.S(s ? BL.dvs : BL.dv), z.B, z.A, ag.v, c.s));
+        const float* mem = s ? a->memory_sub : a->memory;
+        float* dmem = s ? a->d_memory_sub : a->d_memory;
+        const float* DPM = c.S(s ? BL.dpms : BL.dpm);
+        T2_TRY(gemm(matmul_tn(c, DPM, z.A, mem, z.E, ag.wm, z.E, z.A, z.E, z.B * Tin), c.s));
+        // d(memory) = dPM . Wm  +  per item: align^T [Tin x T] . dctx [T x E]
+        T2_TRY(gemm(matmul_nn(DPM, z.A, aw.wm, z.E, dmem, z.E, z.B * Tin, z.E, z.A), c.s));
+        GemmDesc dm = gemm_desc();
+        dm.A = s ? a->align_sub : a->align; dm.sam = 1; dm.sak = Tin; dm.bsA = (long)z.T * Tin;
+        dm.B = c.S(s ? BL.dctxs : BL.dctx); dm.sbk = z.E; dm.sbn = 1; dm.bsB = (long)z.T * z.E;
+        dm.C = dmem; dm.ldc = z.E; dm.bsC = (long)Tin * z.E;
+        dm.M = Tin; dm.N = z.E; dm.K = z.T; dm.batch = z.B; dm.beta = 1.f;
+        T2_TRY(gemm(dm, c.s));
+    }
+    return 0;
 }
 
 int t2_decoder_infer(const t2_dims* dims, const t2_decoder_weights* w, const t2_decoder_infer_args* a, void* stream) {

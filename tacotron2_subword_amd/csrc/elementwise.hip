@@ -68,7 +68,60 @@ __global__ void fill_kernel(float* p, float v, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
+__global__ void relu_drop_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* dz, float scale, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dz[i] = y[i] > 0.f ? dy[i] * scale : 0.f;
+}
+
+// stage 1: block (x = column tile of 64, y = row slab) sums its slab; stage 2 sums the slabs in order
+__global__ void colsum_stage1_kernel(const float* __restrict__ X, long ld, int M, int N, int slabs, float* scratch) {
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;                                  // 4 row phases per block
+    const int rows = (M + slabs - 1) / slabs;
+    const int m0 = blockIdx.y * rows, m1 = min(M, m0 + rows);
+    __shared__ float part[4][64];
+    float acc = 0.f;
+    if (n < N) for (int m = m0 + sub; m < m1; m += 4) acc += X[(long)m * ld + n];
+    part[sub][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (sub == 0 && n < N) scratch[(long)blockIdx.y * N + n] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+__global__ void colsum_stage2_kernel(const float* __restrict__ scratch, int N, int slabs, float* out, float* out2) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int s = 0; s < slabs; ++s) acc += scratch[(long)s * N + n];
+    out[n] = acc;
+    if (out2) out2[n] = acc;
+}
+__global__ void batch_sum_kernel(const float* __restrict__ X, int B, int n, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += X[(long)b * n + i];
+    out[i] = acc;
+}
+
 }  // namespace
+
+int relu_drop_bwd(const float* dy, const float* y, float* dz, float scale, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, dy, y, dz, scale, n);
+    T2_LAUNCH_CHECK();
+    return 0;
+}
+int colsum(const float* X, long ld, int M, int N, float* out, float* out2, float* scratch, hipStream_t s) {
+    const int slabs = M >= 64 * 64 ? 64 : (M >= 64 ? M / 64 : 1);
+    hipLaunchKernelGGL(colsum_stage1_kernel, dim3((N + 63) / 64, slabs), dim3(256), 0, s, X, ld, M, N, slabs, scratch);
+    T2_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, s, scratch, N, slabs, out, out2);
+    T2_LAUNCH_CHECK();
+    return 0;
+}
+int batch_sum(const float* X, int B, int n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(batch_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, s, X, B, n, out);
+    T2_LAUNCH_CHECK();
+    return 0;
+}
 
 int rng_keep_mask(uint64_t seed, uint32_t site, uint32_t n, float p, uint8_t* out, hipStream_t s) {
     hipLaunchKernelGGL(rng_keep_mask_kernel, dim3(grid_for(n)), dim3(256), 0, s, rng_key(seed, site), n, p, out);

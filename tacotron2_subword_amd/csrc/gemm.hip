@@ -45,7 +45,7 @@ __device__ __forceinline__ void epilogue_store(const GemmDesc& d, float* C, int 
 // Load one operand tile (R rows x BK) into registers.  KC: k is the contiguous stride.
 template <int R, bool KC>
 __device__ __forceinline__ void load_tile(const float* __restrict__ base, long srow, long sk, int row0, int nrows,
-                                          int k0, int kend, int vec, f32x4 (&regs)[R * 4 / 256]) {
+                                          int k0, int kend, int vec, int kper, int kph, f32x4 (&regs)[R * 4 / 256]) {
     constexpr int NQ = R * 4 / 256;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -55,7 +55,10 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ base, long s
             int row = row0 + (q >> 2), k = k0 + (q & 3) * 4;
             if (row < nrows) {
                 const float* p = base + (long)row * srow + k;
-                if (vec && k + 3 < kend) {
+                if (kper) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (k + j < kend && (k + j) % kper != kph) v[j] = p[j];
+                } else if (vec && k + 3 < kend) {
                     v = *reinterpret_cast<const f32x4*>(p);
                 } else {
 #pragma unroll
@@ -64,7 +67,7 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ base, long s
             }
         } else {
             int k = k0 + q / (R / 4), row = row0 + (q % (R / 4)) * 4;
-            if (k < kend) {
+            if (k < kend && !(kper && k % kper == kph)) {
                 const float* p = base + (long)k * sk + row;
                 if (vec && row + 3 < nrows) {
                     v = *reinterpret_cast<const f32x4*>(p);
@@ -126,8 +129,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK g) {
 
     f32x4 ra[BM * 4 / 256], rb[BN * 4 / 256];
     if (kbeg < kend) {
-        load_tile<BM, A_KC>(A, d.sam, d.sak, m0, d.M, kbeg, kend, g.avec, ra);
-        load_tile<BN, B_KC>(B, d.sbn, d.sbk, n0, d.N, kbeg, kend, g.bvec, rb);
+        load_tile<BM, A_KC>(A, d.sam, d.sak, m0, d.M, kbeg, kend, g.avec, d.kmask_period, d.kmask_phase, ra);
+        load_tile<BN, B_KC>(B, d.sbn, d.sbk, n0, d.N, kbeg, kend, g.bvec, d.kmask_period, d.kmask_phase, rb);
         store_tile<BM, A_KC>(As[0], ra);
         store_tile<BN, B_KC>(Bs[0], rb);
     }
@@ -136,8 +139,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK g) {
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = k0 + BK < kend;
         if (more) {
-            load_tile<BM, A_KC>(A, d.sam, d.sak, m0, d.M, k0 + BK, kend, g.avec, ra);
-            load_tile<BN, B_KC>(B, d.sbn, d.sbk, n0, d.N, k0 + BK, kend, g.bvec, rb);
+            load_tile<BM, A_KC>(A, d.sam, d.sak, m0, d.M, k0 + BK, kend, g.avec, d.kmask_period, d.kmask_phase, ra);
+            load_tile<BN, B_KC>(B, d.sbn, d.sbk, n0, d.N, k0 + BK, kend, g.bvec, d.kmask_period, d.kmask_phase, rb);
         }
         const float* as = As[cur] + wm * (BM / 2) + r;
         const float* bs = Bs[cur] + wn * (BN / 2) + r;

@@ -23,6 +23,8 @@ struct GemmDesc {
     uint32_t drop_base, drop_mstride;             // drop_mstride 0 -> N
     float* ws; size_t ws_bytes;                   // split-K scratch (nullable -> no split)
     int splitk;                                   // 0 = choose automatically
+    int kmask_period, kmask_phase;                // k rows with k % period == phase count as zero (0 = off):
+                                                  // lets a [B,T,*] operand be used shifted by one step
 };
 inline GemmDesc gemm_desc() {
     GemmDesc d{}; d.batch = 1; d.alpha = 1.f; d.beta = 0.f; d.act = ACT_NONE; d.drop_p = 0.f; return d;
@@ -51,10 +53,36 @@ constexpr int kMaxLstmStreams = 4;
 struct LstmStepDesc { LstmStream st[kMaxLstmStreams]; int nstreams; int B, H; float drop_p; uint64_t seed; };
 int lstm_step_fwd(const LstmStepDesc& d, hipStream_t s);
 
+// Backward of one LSTM step, part 1 (pointwise): total dL/dh_out(t), dL/dc_out(t) -> dL/d(gate pre-activations).
+struct LstmBwdStream {
+    const float* dh1; long lddh1;          // [B,H] direct gradient on h_out(t) (nullable)
+    const float* dh2; long lddh2;          // second direct source (nullable)
+    const float* part; int nparts; long part_stride; long ldpart; int part_col;   // recurrent partials from
+                                           // lstm_bwd_gemm of step t+1: sum_z part[z*part_stride + b*ldpart + part_col + u]
+    const float* dq; long lddq; const float* wq; int A;   // + dq[b,:] . wq[:,u]  (query projection, nullable)
+    const float* gates; long ldgates;      // saved activated gates of step t
+    const float* c_new; long ldc_new;      // saved cell before dropout
+    const float* c_prev; long ldc_prev;    // cell carried INTO step t (after dropout), null -> 0
+    float* dc_state;                       // [B,H] running dL/dc_out, read (unless first) and replaced by dL/dc_prev
+    float* dg; long lddg;                  // [B,4H] out: gradient wrt gate pre-activations
+    uint32_t site_h, site_c, idx_base, idx_bstride;
+};
+struct LstmBwdPointDesc { LstmBwdStream st[kMaxLstmStreams]; int nstreams; int B, H; float drop_p; uint64_t seed; int first; };
+int lstm_bwd_pointwise(const LstmBwdPointDesc& d, hipStream_t s);
+
+// part 2 (skinny GEMM): partial products dL/dx_rec = dg(t) . W for the recurrent input columns,
+// split over column tiles x K-splits so that the whole chip works on one step.
+struct LstmBwdSeg { const float* w; long ldw; int ncols; };
+struct LstmBwdGemmStream { const float* dg; long lddg; LstmBwdSeg seg[3]; int nseg; float* part; };
+struct LstmBwdGemmDesc { LstmBwdGemmStream st[kMaxLstmStreams]; int nstreams; int B, H4, KS, NC; };
+int lstm_bwd_gemm(const LstmBwdGemmDesc& d, hipStream_t s);
+int lstm_bwd_ksplit(int H4);
+
 // ------------------------------------------------------------------ attention (attention.hip)
 struct AttnStream {
     const float* query; long ldq;         // [B,A] processed query (W_q h), or null when qpart is given
     const float* qpart; int nparts;       // [nparts][B][A] partial queries from lstm_step_fwd (summed in order)
+    float* q_out; long ldq_out;           // [B,A] the query actually used, saved for backward (nullable)
     const float* pm;                      // [B,Tin,A] processed memory
     const float* memory;                  // [B,Tin,E]
     const int* lengths;                   // [B] valid memory length (nullable = all valid)
@@ -76,6 +104,26 @@ struct AttnStepDesc {
 };
 int attention_step_fwd(const AttnStepDesc& d, hipStream_t s);
 
+// Backward of one SMA attention step (reverse time).
+struct AttnBwdStream {
+    const float* dctx[3]; long lddctx[3];  // direct gradient sources on ctx(t) [B,E] (nullable entries)
+    const float* part; int nparts; long part_stride; long ldpart; int part_col;   // recurrent partials (ctx columns)
+    const float* dalign; long lddalign;    // optional external gradient on the alignment row [B,Tin]
+    const float* q; long ldq;              // saved query [B,A]
+    const float* pm; const float* memory;  // [B,Tin,A], [B,Tin,E]
+    const float* p; long ldp;              // saved selection probability of step t
+    const float* a_prev; long lda_prev;    // alignment of step t-1 (null at t=0 -> one-hot)
+    const float* v;
+    float* carry;                          // [B,Tin] gradient flowing into a_{t} from step t+1 (in/out)
+    float* dctx_out; long lddctx_out;      // [B,E] total ctx gradient, saved for the d(memory) GEMM
+    float* dq_out; long lddq_out;          // [B,A]
+    float* dv_acc;                         // [B,A] accumulated over steps
+    float* dpm_acc;                        // [B,Tin,A] accumulated over steps
+    int Tin;
+};
+struct AttnBwdDesc { AttnBwdStream st[2]; int nstreams; int B, A, E; int first; };
+int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s);
+
 // ------------------------------------------------------------------ elementwise (elementwise.hip)
 int rng_keep_mask(uint64_t seed, uint32_t site, uint32_t n, float p, uint8_t* out, hipStream_t s);
 int rng_normal(uint64_t seed, uint32_t site, uint32_t n, float* out, hipStream_t s);
@@ -85,5 +133,11 @@ int teacher_inputs(const float* mel, float* X, int B, int M, int T, hipStream_t 
 int transpose_btc_to_bct(const float* in, float* out, int B, int T, int C, const int* lengths, float fill, hipStream_t s);
 int mask_bt(float* x, int B, int T, const int* lengths, float fill, hipStream_t s);
 int fill_f32(float* p, float v, size_t n, hipStream_t s);
+// dz = dy * (y > 0 ? scale : 0)   (ReLU + dropout backward from the saved output; in place allowed)
+int relu_drop_bwd(const float* dy, const float* y, float* dz, float scale, size_t n, hipStream_t s);
+// out[n] = sum_m X[m*ld + n]  (bias gradients; two fixed-order stages, scratch >= 64*N floats); out2 optional copy
+int colsum(const float* X, long ld, int M, int N, float* out, float* out2, float* scratch, hipStream_t s);
+// out[i] = sum_b X[b*n + i]
+int batch_sum(const float* X, int B, int n, float* out, hipStream_t s);
 
 }  // namespace t2

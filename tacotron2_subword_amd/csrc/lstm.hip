@@ -139,6 +139,130 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_fwd_kernel(LstmStepDesc d) 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// backward, part 1: pointwise.  One thread per (b, u).
+//   dh  = direct sources + sum of recurrent partials (+ dq . Wq)          gradient on h_out(t)
+//   dhn = dh * keep_h/(1-p) ;  dcn = dc_out * keep_c/(1-p) + dhn * o * (1 - tanh(cn)^2)
+//   d(pre-activations) = { dcn*g*i(1-i), dcn*c_prev*f(1-f), dcn*i*(1-g^2), dhn*tanh(cn)*o(1-o) }
+//   dc_state <- dcn * f                                                    gradient on c_out(t-1)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(LstmBwdPointDesc d) {
+    const LstmBwdStream& st = d.st[blockIdx.y];
+    const int B = d.B, H = d.H;
+    const long i = blockIdx.x * 256l + threadIdx.x;
+    if (i >= (long)B * H) return;
+    const int b = (int)(i / H), u = (int)(i % H);
+    float dh = 0.f;
+    if (st.dh1) dh += st.dh1[(long)b * st.lddh1 + u];
+    if (st.dh2) dh += st.dh2[(long)b * st.lddh2 + u];
+    if (st.part && !d.first) {
+        const float* p = st.part + (long)b * st.ldpart + st.part_col + u;
+        float acc = 0.f;
+        for (int z = 0; z < st.nparts; ++z) acc += p[(long)z * st.part_stride];
+        dh += acc;
+    }
+    if (st.dq) {
+        const float* q = st.dq + (long)b * st.lddq;
+        const float* w = st.wq + u;
+        float acc = 0.f;
+        for (int a = 0; a < st.A; ++a) acc += q[a] * w[(long)a * H];
+        dh += acc;
+    }
+    float dc = d.first ? 0.f : st.dc_state[i];
+    if (d.drop_p > 0.f) {
+        const uint32_t idx = st.idx_base + (uint32_t)b * st.idx_bstride + (uint32_t)u;
+        const float scale = 1.0f / (1.0f - d.drop_p);
+        dh = rng_keep(rng_key(d.seed, st.site_h), idx, d.drop_p) ? dh * scale : 0.f;
+        dc = rng_keep(rng_key(d.seed, st.site_c), idx, d.drop_p) ? dc * scale : 0.f;
+    }
+    const float* gp = st.gates + (long)b * st.ldgates + u;
+    const float ig = gp[0], fg = gp[H], gg = gp[2 * H], og = gp[3 * H];
+    const float cn = st.c_new[(long)b * st.ldc_new + u];
+    const float cp = st.c_prev ? st.c_prev[(long)b * st.ldc_prev + u] : 0.f;
+    const float tc = tanhf(cn);
+    const float dcn = dc + dh * og * (1.0f - tc * tc);
+    float* dg = st.dg + (long)b * st.lddg + u;
+    dg[0] = dcn * gg * ig * (1.0f - ig);
+    dg[H] = dcn * cp * fg * (1.0f - fg);
+    dg[2 * H] = dcn * ig * (1.0f - gg * gg);
+    dg[3 * H] = dh * tc * og * (1.0f - og);
+    st.dc_state[i] = dcn * fg;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, part 2: part[z][b][n] = sum_{k in K-split z} dg[b,k] * W[k,n]   for the recurrent
+// input columns n (ctx | h for the attention LSTMs, h for the decoder / encoder LSTMs).
+// grid = (column tiles of 32, K-splits, streams); inside a workgroup the K range is split again
+// over NW waves (v_mfma_f32_32x32x2_f32, operands from global memory) and summed through LDS.
+// ---------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(NW * 64) void lstm_bwd_gemm_kernel(LstmBwdGemmDesc d) {
+    const LstmBwdGemmStream& st = d.st[blockIdx.z];
+    const int B = d.B;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hk = lane >> 5;
+    // locate this column tile
+    int col0 = blockIdx.x * 32, sidx = 0, cbase = 0;
+    while (sidx < st.nseg - 1 && col0 >= cbase + st.seg[sidx].ncols) { cbase += st.seg[sidx].ncols; ++sidx; }
+    const LstmBwdSeg sg = st.seg[sidx];
+    const int kspan = d.H4 / d.KS, kw = kspan / NW;
+    const int kbeg = blockIdx.y * kspan + wave * kw;
+    const float* wp = sg.w + (long)(kbeg + 4 * hk) * sg.ldw + (col0 - cbase) + r;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* part = smem;                              // [NW][32][PP]
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+    const float* xp[MT];
+    bool xv[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int row = m * 32 + r;
+        xv[m] = row < B;
+        xp[m] = st.dg + (long)(xv[m] ? row : 0) * st.lddg + kbeg + 4 * hk;
+    }
+#pragma unroll 2
+    for (int k = 0; k < kw; k += 8) {
+        float w4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w4[j] = wp[(long)(k + j) * sg.ldw];
+        f32x4 x4[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            x4[m] = *reinterpret_cast<const f32x4*>(xp[m] + k);
+            if (!xv[m]) x4[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(x4[m][j], w4[j], acc[m], 0, 0, 0);
+    }
+    float* out = st.part + (long)blockIdx.y * B * d.NC;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (m > 0) __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            part[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk) * PP + r] = acc[m][e];
+        __syncthreads();
+        for (int i = threadIdx.x; i < 32 * 32; i += NW * 64) {
+            const int bl = i >> 5, c = i & 31, b = m * 32 + bl;
+            if (b < B) {
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sum += part[(w * 32 + bl) * PP + c];
+                out[(long)b * d.NC + col0 + c] = sum;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int lstm_step_fwd(const LstmStepDesc& d, hipStream_t s) {
@@ -163,6 +287,46 @@ int lstm_step_fwd(const LstmStepDesc& d, hipStream_t s) {
     else if (MT <= 2) hipLaunchKernelGGL(lstm_step_fwd_kernel<2>, grid, block, smem(2), s, d);
     else if (MT <= 4) hipLaunchKernelGGL(lstm_step_fwd_kernel<4>, grid, block, smem(4), s, d);
     else hipLaunchKernelGGL(lstm_step_fwd_kernel<8>, grid, block, smem(8), s, d);
+    T2_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace t2
+
+namespace t2 {
+
+int lstm_bwd_pointwise(const LstmBwdPointDesc& d, hipStream_t s) {
+    T2_REQUIRE(d.nstreams >= 1 && d.nstreams <= kMaxLstmStreams, "lstm_bwd_pointwise: nstreams=%d", d.nstreams);
+    const long n = (long)d.B * d.H;
+    hipLaunchKernelGGL(lstm_bwd_pointwise_kernel, dim3((unsigned)((n + 255) / 256), d.nstreams), dim3(256), 0, s, d);
+    T2_LAUNCH_CHECK();
+    return 0;
+}
+
+int lstm_bwd_ksplit(int H4) {
+    int ks = 8;
+    while (ks > 1 && H4 % (ks * NW * 8) != 0) ks >>= 1;
+    return ks;
+}
+
+int lstm_bwd_gemm(const LstmBwdGemmDesc& d, hipStream_t s) {
+    T2_REQUIRE(d.nstreams >= 1 && d.nstreams <= kMaxLstmStreams, "lstm_bwd_gemm: nstreams=%d", d.nstreams);
+    T2_REQUIRE(d.B >= 1 && d.B <= 256, "lstm_bwd_gemm: batch %d", d.B);
+    T2_REQUIRE(d.KS >= 1 && d.H4 % (d.KS * NW * 8) == 0, "lstm_bwd_gemm: 4H=%d not divisible by KS*64 (KS=%d)", d.H4, d.KS);
+    int nc = 0;
+    for (int j = 0; j < d.st[0].nseg; ++j) nc += d.st[0].seg[j].ncols;
+    T2_REQUIRE(nc == d.NC && nc % 32 == 0, "lstm_bwd_gemm: column count %d (NC=%d) must be a multiple of 32", nc, d.NC);
+    for (int i = 0; i < d.nstreams; ++i) {
+        T2_REQUIRE(d.st[i].lddg % 4 == 0 && ((uintptr_t)d.st[i].dg & 15) == 0, "lstm_bwd_gemm: dg must be 16-byte aligned");
+        for (int j = 0; j < d.st[i].nseg; ++j) T2_REQUIRE(d.st[i].seg[j].ncols % 32 == 0, "lstm_bwd_gemm: segment cols %d", d.st[i].seg[j].ncols);
+    }
+    const int MT = (d.B + 31) / 32;
+    dim3 grid(d.NC / 32, d.KS, d.nstreams), block(NW * 64);
+    const size_t smem = (size_t)NW * 32 * PP * sizeof(float);
+    if (MT <= 1) hipLaunchKernelGGL(lstm_bwd_gemm_kernel<1>, grid, block, smem, s, d);
+    else if (MT <= 2) hipLaunchKernelGGL(lstm_bwd_gemm_kernel<2>, grid, block, smem, s, d);
+    else if (MT <= 4) hipLaunchKernelGGL(lstm_bwd_gemm_kernel<4>, grid, block, smem, s, d);
+    else hipLaunchKernelGGL(lstm_bwd_gemm_kernel<8>, grid, block, smem, s, d);
     T2_LAUNCH_CHECK();
     return 0;
 }

@@ -77,6 +77,24 @@ def decoder_forward(W: L.DecoderWeights, dims: L.Dims, memory, memory_sub, mem_l
     return dp
 
 
+def decoder_backward(W: L.DecoderWeights, P: dict, dims: L.Dims, dp: DecoderPass, memory, memory_sub, d_mel, d_gate, *,
+                     training: bool, prenet_dropout: bool, seed: int, d_align=None, d_align_sub=None, prefix="decoder."):
+    """Backward of decoder_forward.  P: the (reference-keyed) weight dict, used for gradient shapes.
+    Returns (grads dict keyed like P, d_memory, d_memory_sub)."""
+    dev = memory.device
+    G = {prefix + k: torch.empty_like(P[prefix + k]) for k in L.DECODER_PARAM_KEYS_SMA}
+    GS = L.decoder_grads(G, prefix)
+    bl = L.decoder_bwd_layout(dims, dp.B, dp.T, dp.Tin, dp.Tsub)
+    bws = torch.empty(bl.total_floats, dtype=torch.float32, device=dev)
+    d_mem = torch.empty_like(memory)
+    d_mem_sub = torch.empty_like(memory_sub)
+    a = L.DecoderBwdArgs(dp.B, dp.T, dp.Tin, dp.Tsub, L.ptr(memory), L.ptr(memory_sub), L.ptr(dp.align), L.ptr(dp.align_sub),
+                         L.ptr(d_mel), L.ptr(d_gate), L.ptr(d_align), L.ptr(d_align_sub), L.ptr(d_mem), L.ptr(d_mem_sub),
+                         L.ptr(dp.ws), L.ptr(bws), int(training), int(prenet_dropout), seed)
+    L.check(L.lib().t2_decoder_backward(C.byref(dims), C.byref(W), C.byref(GS), C.byref(a), L.stream()))
+    return G, d_mem, d_mem_sub
+
+
 def decoder_infer(W: L.DecoderWeights, dims: L.Dims, memory, memory_sub, *, max_steps: int, gate_threshold: float,
                   prenet_dropout: bool, seed: int = 0, poll_every: int = 16, mem_lengths=None, sub_lengths=None):
     """Autoregressive decode (Decoder.inference, model.py:430-492) for any B.
