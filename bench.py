@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: mel-frames/s of the full training iteration (forward + loss + backward +
+gradient clip + Adam; train.py:293-340 of the reference) at tensor batch B=64 per GPU, default
+hparams (512-dim / 80-mel, dual-stream BERT_Tacotron2, StepwiseMonotonicAttention), synthetic
+LJSpeech-shaped batches (100 phones, 60 sub-word tokens, 400 frames) — BASELINE.json configs[1];
+with --gpus N: configs[2] (data parallel over RCCL, weak scaling, one process per GPU).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     dominant decoder kernel: algorithmic FLOPs per launch / its average duration,
+               measured with HIP events on the launch stream in one extra (untimed) profiled step
+  cpu_baseline the CPU oracle (torch-CPU restatement of the reference, oracle/) timed on this
+               box's host cores on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# peaks from /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def decoder_step_flops(hp, B, Tin, Tsub):
+    """Algorithmic FLOPs of the per-step kernels: 2 * MACs."""
+    P, E, Ha, Hd, A = hp.prenet_dim, hp.encoder_embedding_dim, hp.attention_rnn_dim, hp.decoder_rnn_dim, hp.attention_dim
+    att_lstm_fwd = 2 * 2 * B * (E + Ha) * 4 * Ha + 2 * 2 * B * Ha * A       # recurrent half of both cells + query projection
+    dec_lstm_fwd = 2 * B * Hd * 4 * Hd                                       # recurrent half (input half is a hoisted GEMM)
+    return dict(att_lstm_fwd=att_lstm_fwd, dec_lstm_fwd=dec_lstm_fwd,
+                att_lstm_bwd_gemm=2 * 2 * B * 4 * Ha * (E + Ha), dec_lstm_bwd_gemm=2 * B * 4 * Hd * Hd)
+
+
+def decoder_step_bytes(hp, B, Tin, Tsub):
+    """Algorithmic bytes per launch (fp32): weights once + activations once."""
+    P, E, Ha, Hd, A = hp.prenet_dim, hp.encoder_embedding_dim, hp.attention_rnn_dim, hp.decoder_rnn_dim, hp.attention_dim
+    att = 2 * (4 * Ha * (E + Ha) + A * Ha) * 4 + 2 * B * (E + Ha + 4 * Ha + 4 * Ha + 3 * Ha + Ha // 8 * A) * 4
+    dec = 4 * Hd * Hd * 4 + B * (Hd + 4 * Hd + 4 * Hd + 3 * Hd) * 4
+    attn = B * (Tin + Tsub) * (E + A) * 4
+    return dict(att_lstm_fwd=att, dec_lstm_fwd=dec, attention_fwd=attn, attention_bwd=2 * attn,
+                att_lstm_bwd_gemm=2 * 4 * Ha * (E + Ha) * 4, dec_lstm_bwd_gemm=4 * Hd * Hd * 4)
+
+
+def cpu_baseline(B=4, Tin=100, Tsub=60, T=50, reps=1):
+    """Reported baseline, not the target: the oracle's fp32 training iteration (forward + loss +
+    backward + clip + Adam) on the host cores, bounded sample."""
+    from oracle import recipe
+    from oracle import tacotron2_oracle as O
+    hp = O.default_hparams()
+    P = recipe.make_weights(hp)
+    params = []
+    for k, v in P.items():
+        if v.is_floating_point() and "running" not in k and not k.startswith("decoder.decoder_rnn_bert"):
+            v.requires_grad_(True)
+            params.append(v)
+    opt = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-6)
+    x, y = recipe.parse_batch(recipe.make_batch(hp, B, Tin, Tsub, T))
+    rnd = recipe.make_rnd(hp, B, Tin, Tsub, T)
+    cores = torch.get_num_threads()
+    best = None
+    for _ in range(reps + 1):                      # first pass warms the allocator / thread pool
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        out = O.forward(P, hp, x, training=True, rnd=rnd, new_stats={})
+        loss, _, _ = O.loss(out, y)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return dict(value=B * T / best, unit="mel-frames/s", cores=cores, kind="port",
+                sample=f"oracle training iteration (fwd+loss+bwd+clip+Adam), fp32, B={B} Tin={Tin} Tsub={Tsub} T={T}, "
+                       f"best of {reps + 1} ({best:.2f} s)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--tin", type=int, default=100)
+    ap.add_argument("--tsub", type=int, default=60)
+    ap.add_argument("--frames", type=int, default=400)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    if world != a.gpus:
+        if a.gpus != 1 and world == 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+
+    from tacotron2_subword_amd import _lib as L
+    from tacotron2_subword_amd.hparams import create_hparams
+    from tacotron2_subword_amd import train as T
+
+    hp = create_hparams()
+    hp.distributed_run = world > 1
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+    model, optimizer, criterion = T.make_training_objects(hp)
+    model.train()
+    B, Tin, Tsub, Tn = a.batch, a.tin, a.tsub, a.frames
+    batch = T.synthetic_batch(hp, B, Tin, Tsub, Tn, seed=1234 + rank)
+    x, y = model.parse_batch(batch)                 # inputs resident in HBM before the timed region
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    it = 0
+    for _ in range(a.warmup):
+        T.train_step(model, criterion, optimizer, x, y, hp, it)
+        it += 1
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = T.train_step(model, criterion, optimizer, x, y, hp, it)
+        it += 1
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss_val = float(loss.item())
+
+    # one extra, untimed, profiled step: HIP events around every per-step decoder kernel launch
+    roof, kernels = None, None
+    if rank == 0:
+        L.prof_enable(8 * Tn + 64)
+        T.train_step(model, criterion, optimizer, x, y, hp, it)
+        prof = L.prof_collect()
+        torch.cuda.synchronize()
+        fl, by = decoder_step_flops(hp, B, Tin, Tsub), decoder_step_bytes(hp, B, Tin, Tsub)
+        kernels = {}
+        for k, (ms, n) in prof.items():
+            if n == 0:
+                continue
+            avg_us = 1e3 * ms / n
+            e = dict(launches=n, avg_us=round(avg_us, 2), total_ms=round(ms, 2))
+            if k in fl:
+                e["tflops"] = round(fl[k] / (avg_us * 1e-6) / 1e12, 2)
+            if k in by:
+                e["gbs"] = round(by[k] / (avg_us * 1e-6) / 1e9, 1)
+            kernels[k] = e
+        dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
+        if dom in fl:
+            roof = dict(kernel=dom, bound="mfma", achieved=kernels[dom]["tflops"], peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=round(kernels[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                        note="fp32 MFMA (v_mfma_f32_32x32x2_f32) peak; algorithmic FLOPs per launch / avg HIP-event duration")
+        else:
+            roof = dict(kernel=dom, bound="hbm", achieved=kernels[dom]["gbs"], peak=PEAK_HBM_GBS, unit="GB/s",
+                        frac=round(kernels[dom]["gbs"] / PEAK_HBM_GBS, 4), traffic=None)
+
+    if world > 1:
+        torch.distributed.barrier()
+    if rank != 0:
+        return
+    frames = world * B * Tn * a.steps
+    out = {
+        "metric": "mel_frames_per_sec_train", "value": round(frames / dt, 1), "unit": "mel-frames/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BERT_Tacotron2 default hparams (SMA), full training iteration fwd+loss+bwd+clip+Adam, "
+                               f"B={B}/GPU, {Tin} phones, {Tsub} sub-word tokens, {Tn} frames, 80-mel",
+                   "global_batch": world * B, "frames_per_item": Tn, "parallelism": f"dp{world}",
+                   "hip_kernels": "decoder fwd+bwd (prenets, attention LSTMs, SMA, decoder LSTM, projections)",
+                   "interim_torch_ops": "encoder conv/BN/BiLSTM, postnet conv/BN, loss, clip, Adam"},
+        "loss": round(loss_val, 5),
+        "roofline": roof, "kernels": kernels,
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

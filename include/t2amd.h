@@ -176,6 +176,15 @@ int t2_decoder_infer(const t2_dims* dims, const t2_decoder_weights* w, const t2_
 int t2_finalize_bct(const float* in_btc, float* out_bct, int B, int T, int C, const int32_t* lengths, float fill, void* stream);
 int t2_mask_bt(float* x, int B, int T, const int32_t* lengths, float fill, void* stream);
 
+/* In-situ kernel timing for bench.py's roofline figures: after t2_prof_enable(n) the decoder
+ * drivers bracket each per-step kernel launch with HIP events on the launch stream (up to n
+ * launches); t2_prof_collect synchronises on the last event and returns total milliseconds and
+ * launch counts per kernel kind (host arrays of >= 8 entries):
+ * 0 att-LSTM fwd, 1 attention fwd, 2 dec-LSTM fwd, 3 attention bwd, 4 att-LSTM bwd pointwise,
+ * 5 att-LSTM bwd GEMM, 6 dec-LSTM bwd pointwise, 7 dec-LSTM bwd GEMM. */
+int t2_prof_enable(int max_launches);
+int t2_prof_collect(int n_kinds, double* total_ms_host, int* launches_host);
+
 /* Unit-testable pieces. */
 int t2_gemm(const float* A, const float* B, float* C, int M, int N, int K,
             long sam, long sak, long sbn, long sbk, long ldc,

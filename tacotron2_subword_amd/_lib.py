@@ -103,7 +103,7 @@ class DecoderBwdArgs(C.Structure):
 
 # every symbol include/t2amd.h declares (tests/test_abi.py checks the library exports them all)
 EXPORTS = ["t2_last_error", "t2_version", "t2_decoder_layout_query", "t2_decoder_forward", "t2_decoder_infer",
-           "t2_decoder_bwd_layout_query", "t2_decoder_backward",
+           "t2_decoder_bwd_layout_query", "t2_decoder_backward", "t2_prof_enable", "t2_prof_collect",
            "t2_finalize_bct", "t2_mask_bt", "t2_gemm", "t2_rng_keep_mask", "t2_rng_normal"]
 
 _lib = None
@@ -128,6 +128,8 @@ def lib() -> C.CDLL:
         L.t2_decoder_bwd_layout_query.argtypes = [C.POINTER(Dims), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(DecoderBwdLayout)]
         L.t2_decoder_backward.argtypes = [C.POINTER(Dims), C.POINTER(DecoderWeights), C.POINTER(DecoderGrads),
                                           C.POINTER(DecoderBwdArgs), C.c_void_p]
+        L.t2_prof_enable.argtypes = [C.c_int]
+        L.t2_prof_collect.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.t2_finalize_bct.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p]
         L.t2_mask_bt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p]
         _lib = L
@@ -195,6 +197,21 @@ DECODER_PARAM_KEYS_SMA = [
     "gate_layer.linear_layer.weight", "gate_layer.linear_layer.bias"]
 
 
+def _lsa_keys():
+    out = []
+    for k in DECODER_PARAM_KEYS_SMA:
+        if k.endswith(".v.weight"):
+            n = k[:-len(".v.weight")]
+            out += [n + ".v.linear_layer.weight", n + ".location_layer.location_conv.conv.weight",
+                    n + ".location_layer.location_dense.linear_layer.weight"]
+        else:
+            out.append(k)
+    return out
+
+
+DECODER_PARAM_KEYS_LSA = _lsa_keys()
+
+
 def decoder_grads(G: dict, prefix: str = "decoder.") -> DecoderGrads:
     """Pack pointers of gradient buffers keyed like the weights (SMA parameter set)."""
     p = lambda k: ptr(G[prefix + k])
@@ -218,3 +235,19 @@ def decoder_layout(dims: Dims, B: int, T: int, Tin: int, Tsub: int) -> DecoderLa
     L = DecoderLayout()
     check(lib().t2_decoder_layout_query(C.byref(dims), B, T, Tin, Tsub, C.byref(L)))
     return L
+
+
+PROF_KINDS = ["att_lstm_fwd", "attention_fwd", "dec_lstm_fwd", "attention_bwd", "att_lstm_bwd_pointwise",
+              "att_lstm_bwd_gemm", "dec_lstm_bwd_pointwise", "dec_lstm_bwd_gemm"]
+
+
+def prof_enable(max_launches: int) -> None:
+    check(lib().t2_prof_enable(max_launches))
+
+
+def prof_collect() -> dict:
+    """{kind: (total_ms, launches)} of the launches recorded since prof_enable (HIP events on the launch stream)."""
+    n = len(PROF_KINDS)
+    ms, cnt = (C.c_double * n)(), (C.c_int * n)()
+    check(lib().t2_prof_collect(n, ms, cnt))
+    return {k: (ms[i], cnt[i]) for i, k in enumerate(PROF_KINDS)}

@@ -1,0 +1,40 @@
+"""Attention modules as PARAMETER CONTAINERS with the reference's constructor signature and
+state_dict keys (attention.py:7-85, 291-398).  The arithmetic runs inside the fused HIP decoder
+(csrc/attention.hip); these classes are never called step by step."""
+from torch import nn
+
+from .layers import ConvNorm, LinearNorm
+
+
+class LocationLayer(nn.Module):
+    def __init__(self, attention_n_filters, attention_kernel_size, attention_dim):
+        super().__init__()
+        self.location_conv = ConvNorm(2, attention_n_filters, kernel_size=attention_kernel_size,
+                                      padding=int((attention_kernel_size - 1) / 2), bias=False, stride=1, dilation=1)
+        self.location_dense = LinearNorm(attention_n_filters, attention_dim, bias=False, w_init_gain="tanh")
+
+
+class LocationSensitiveAttention(nn.Module):
+    kind = "LSA"
+
+    def __init__(self, attention_rnn_dim, embedding_dim, attention_dim, attention_location_n_filters,
+                 attention_location_kernel_size):
+        super().__init__()
+        self.query_layer = LinearNorm(attention_rnn_dim, attention_dim, bias=False, w_init_gain="tanh")
+        self.memory_layer = LinearNorm(embedding_dim, attention_dim, bias=False, w_init_gain="tanh")
+        self.v = LinearNorm(attention_dim, 1, bias=False)
+        self.location_layer = LocationLayer(attention_location_n_filters, attention_location_kernel_size, attention_dim)
+        self.score_mask_value = -float("inf")
+
+
+class StepwiseMonotonicAttention(nn.Module):
+    kind = "SMA"
+
+    def __init__(self, attention_rnn_dim, embedding_dim, attention_dim, attention_location_n_filters,
+                 attention_location_kernel_size):
+        super().__init__()
+        self.memory_layer = LinearNorm(embedding_dim, attention_dim, bias=False, w_init_gain="tanh")
+        self.score_mask_value = -float("inf")
+        self.v = nn.Linear(attention_dim, 1, bias=False)
+        self.query_layer = LinearNorm(attention_rnn_dim, attention_dim, bias=False, w_init_gain="tanh")
+        self.sigmoid_noise = 2.0

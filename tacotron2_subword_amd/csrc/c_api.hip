@@ -22,7 +22,33 @@ void t2_set_error(const char* fmt, ...) {
         if (rc_ != 0) return rc_;   \
     } while (0)
 
+#include <vector>
+
 using namespace t2;
+
+// ---------------------------------------------------------------------------------------------
+// Optional in-situ kernel timing (bench.py's roofline figures): when enabled, the drivers bracket
+// the per-step kernel launches with HIP events on the launch stream.  Off by default.
+// ---------------------------------------------------------------------------------------------
+enum ProfKind { PK_LSTM_ATT_FWD = 0, PK_ATTN_FWD, PK_LSTM_DEC_FWD, PK_ATTN_BWD, PK_LSTM_ATT_BWD_PW, PK_LSTM_ATT_BWD_GEMM,
+                PK_LSTM_DEC_BWD_PW, PK_LSTM_DEC_BWD_GEMM, PK_COUNT };
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> kind;
+    size_t used = 0;
+};
+static Prof g_prof;
+
+struct ProfScope {
+    hipStream_t s; bool on;
+    ProfScope(int kind, hipStream_t st) : s(st), on(g_prof.on && g_prof.used + 2 <= g_prof.ev.size()) {
+        if (on) { g_prof.kind[g_prof.used / 2] = kind; (void)hipEventRecord(g_prof.ev[g_prof.used], s); }
+    }
+    ~ProfScope() {
+        if (on) { (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s); g_prof.used += 2; }
+    }
+};
 
 namespace {
 
@@ -141,6 +167,7 @@ int att_lstm_step(const Dec& c, int t) {
         st.wq = s ? c.w.attn_sub.wq : c.w.attn.wq; st.A = z.A;
         st.qpart = c.P(L.qpart) + (size_t)s * (z.Ha / 8) * z.B * z.A;
     }
+    ProfScope ps(PK_LSTM_ATT_FWD, c.s);
     return lstm_step_fwd(d, c.s);
 }
 
@@ -178,6 +205,7 @@ int attention_step(const Dec& c, int t) {
         st.site_noise = s ? T2_SITE_NOISE_SUB : T2_SITE_NOISE;
         st.idx_base = (uint32_t)t * Tin; st.idx_bstride = (uint32_t)z.T * Tin;
     }
+    ProfScope ps(PK_ATTN_FWD, c.s);
     return attention_step_fwd(d, c.s);
 }
 
@@ -206,6 +234,7 @@ int dec_lstm_step(const Dec& c, int t) {
     st.h_out = c.P(L.dout) + (long)t * z.WO; st.ldh_out = ldO;
     st.site_h = T2_SITE_DEC_H; st.site_c = T2_SITE_DEC_C;
     st.idx_base = (uint32_t)t * z.Hd; st.idx_bstride = (uint32_t)z.T * z.Hd;
+    ProfScope ps(PK_LSTM_DEC_FWD, c.s);
     return lstm_step_fwd(d, c.s);
 }
 
@@ -308,13 +337,14 @@ int dec_bwd_step(const Bwd& c, int t) {
     st.dg = c.S(c.BL.dgd) + (long)t * 4 * z.Hd; st.lddg = (long)z.T * 4 * z.Hd;
     st.site_h = T2_SITE_DEC_H; st.site_c = T2_SITE_DEC_C;
     st.idx_base = (uint32_t)t * z.Hd; st.idx_bstride = (uint32_t)z.T * z.Hd;
-    T2_TRY(lstm_bwd_pointwise(p, c.s));
+    { ProfScope ps(PK_LSTM_DEC_BWD_PW, c.s); T2_TRY(lstm_bwd_pointwise(p, c.s)); }
     if (t == 0) return 0;
     LstmBwdGemmDesc g{};
     g.nstreams = 1; g.B = z.B; g.H4 = 4 * z.Hd; g.KS = ks; g.NC = z.Hd;
     g.st[0].dg = st.dg; g.st[0].lddg = st.lddg;
     g.st[0].seg[0] = LstmBwdSeg{c.w.dec.w_hh, (long)z.Hd, z.Hd}; g.st[0].nseg = 1;
     g.st[0].part = c.S(c.BL.partd);
+    ProfScope ps(PK_LSTM_DEC_BWD_GEMM, c.s);
     return lstm_bwd_gemm(g, c.s);
 }
 
@@ -348,7 +378,7 @@ int att_bwd_step(const Bwd& c, int t) {
         st.dv_acc = c.S(s ? c.BL.dvs : c.BL.dv);
         st.dpm_acc = c.S(s ? c.BL.dpms : c.BL.dpm);
     }
-    T2_TRY(attention_step_bwd(ab, c.s));
+    { ProfScope ps(PK_ATTN_BWD, c.s); T2_TRY(attention_step_bwd(ab, c.s)); }
     // 2. LSTM pointwise backward
     LstmBwdPointDesc p{};
     p.nstreams = 2; p.B = z.B; p.H = z.Ha; p.seed = c.a.seed; p.first = first;
@@ -368,7 +398,7 @@ int att_bwd_step(const Bwd& c, int t) {
         st.site_h = s ? T2_SITE_ATT_H_SUB : T2_SITE_ATT_H; st.site_c = s ? T2_SITE_ATT_C_SUB : T2_SITE_ATT_C;
         st.idx_base = (uint32_t)t * z.Ha; st.idx_bstride = (uint32_t)z.T * z.Ha;
     }
-    T2_TRY(lstm_bwd_pointwise(p, c.s));
+    { ProfScope ps(PK_LSTM_ATT_BWD_PW, c.s); T2_TRY(lstm_bwd_pointwise(p, c.s)); }
     if (t == 0) return 0;
     // 3. recurrent-input gradients of this step: dg(t) . [W_ih[:, P:] | W_hh]  ->  partials for step t-1
     LstmBwdGemmDesc g{};
@@ -381,6 +411,7 @@ int att_bwd_step(const Bwd& c, int t) {
         g.st[s].nseg = 2;
         g.st[s].part = c.S(c.BL.parta) + (size_t)s * ks * z.B * NC;
     }
+    ProfScope ps(PK_LSTM_ATT_BWD_GEMM, c.s);
     return lstm_bwd_gemm(g, c.s);
 }
 
@@ -578,6 +609,37 @@ int t2_decoder_infer(const t2_dims* dims, const t2_decoder_weights* w, const t2_
         }
     }
     *a->steps_run_host = steps;
+    return 0;
+}
+
+
+int t2_prof_enable(int max_launches) {
+    if (max_launches <= 0) { g_prof.on = false; return 0; }
+    const size_t need = (size_t)max_launches * 2;
+    while (g_prof.ev.size() < need) {
+        hipEvent_t e;
+        T2_CHECK_HIP(hipEventCreate(&e));
+        g_prof.ev.push_back(e);
+    }
+    g_prof.kind.assign(g_prof.ev.size() / 2, 0);
+    g_prof.used = 0;
+    g_prof.on = true;
+    return 0;
+}
+
+int t2_prof_collect(int n_kinds, double* total_ms_host, int* launches_host) {
+    T2_REQUIRE(n_kinds >= PK_COUNT, "t2_prof_collect: need %d kinds", (int)PK_COUNT);
+    g_prof.on = false;
+    for (int i = 0; i < n_kinds; ++i) { total_ms_host[i] = 0.0; launches_host[i] = 0; }
+    if (g_prof.used == 0) return 0;
+    T2_CHECK_HIP(hipEventSynchronize(g_prof.ev[g_prof.used - 1]));
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        float ms = 0.f;
+        T2_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]));
+        total_ms_host[g_prof.kind[i / 2]] += ms;
+        launches_host[g_prof.kind[i / 2]] += 1;
+    }
+    g_prof.used = 0;
     return 0;
 }
 

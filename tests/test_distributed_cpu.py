@@ -1,0 +1,91 @@
+"""world_size-2 gloo test (CPU) of the data-parallel wrapper that replaces the reference's
+apply_gradient_allreduce (distributed.py:132-179): broadcast at wrap time, sum/N of gradients,
+dead parameters keep grad None, zero_grad keeps the arena, wrapping twice is harmless."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+
+class Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(6, 5)
+        self.dead = nn.Linear(3, 3)         # never used, like decoder_rnn_bert (model.py:197-199)
+        self.b = nn.Linear(5, 2)
+        self.bn = nn.BatchNorm1d(5)
+
+    def forward(self, x):
+        return self.b(self.bn(torch.tanh(self.a(x))))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tacotron2_subword_amd.distributed import apply_gradient_allreduce
+        torch.manual_seed(100 + rank)                    # different init per rank -> broadcast must fix it
+        m = Toy()
+        m = apply_gradient_allreduce(m)
+        m = apply_gradient_allreduce(m)                  # train.py:81 and :219 both wrap
+        assert isinstance(m, Toy)
+        sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {k: v.tolist() for k, v in sd0.items()})
+        assert gathered[0] == gathered[1], "state not broadcast from rank 0"
+        res = []
+        for step in range(3):
+            m.zero_grad()
+            g = torch.Generator().manual_seed(7 * step + rank)
+            x = torch.randn(4, 6, generator=g)
+            loss = m(x).pow(2).sum()
+            loss.backward()
+            # reference result: average over ranks of the local gradients
+            ref = Toy()
+            ref.load_state_dict(sd0)
+            loc = []
+            for r in range(world):
+                ref.zero_grad()
+                gr = torch.Generator().manual_seed(7 * step + r)
+                ref(torch.randn(4, 6, generator=gr)).pow(2).sum().backward()
+                loc.append({k: p.grad.clone() for k, p in ref.named_parameters() if p.grad is not None})
+            for k, p in m.named_parameters():
+                if k.startswith("dead"):
+                    assert p.grad is None, "dead parameter must keep grad None"
+                    continue
+                want = sum(l[k] for l in loc) / world
+                assert torch.allclose(p.grad, want, atol=1e-6), (step, k)
+                assert p.grad.data_ptr() == m._t2_arena.view(p).data_ptr(), "grad must live in the arena"
+            res.append(float(loss))
+        q.put((rank, "ok", res))
+    except Exception as e:  # noqa
+        import traceback
+        q.put((rank, "fail", traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, info in out:
+        assert status == "ok", f"rank {rank}: {info}"
