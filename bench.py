@@ -50,7 +50,7 @@ def decoder_step_bytes(hp, B, Tin, Tsub):
                 att_lstm_bwd_gemm=2 * 4 * Ha * (E + Ha) * 4, dec_lstm_bwd_gemm=4 * Hd * Hd * 4)
 
 
-def cpu_baseline(B=4, Tin=100, Tsub=60, T=50, reps=1):
+def cpu_baseline(B=64, Tin=100, Tsub=60, T=16, reps=1):
     """Reported baseline, not the target: the oracle's fp32 training iteration (forward + loss +
     backward + clip + Adam) on the host cores, bounded sample."""
     from oracle import recipe

@@ -73,20 +73,22 @@ typedef struct t2_decoder_weights {
     const float *gate_w, *gate_b;                /* decoder.gate_layer.linear_layer.{weight,bias} */
 } t2_decoder_weights;
 
-/* Saved-activation workspace of one decoder pass.  Offsets are in floats from `ws`. */
+/* Saved-activation workspace of one decoder pass.  Offsets are in floats from `ws`.
+ * Per-frame buffers are TIME-MAJOR [T,B,*] (one step's rows are contiguous: the per-step kernels
+ * then touch one or two pages instead of B pages); the alignment-shaped ones stay [B,T,Tin]. */
 typedef struct t2_decoder_layout {
     size_t total_floats;
-    size_t x, p1, p2, p1s, p2s;      /* [B,T,n_mel], prenet activations [B,T,prenet] */
+    size_t x, p1, p2, p1s, p2s;      /* [T,B,n_mel], prenet activations [T,B,prenet] */
     size_t pm, pms;                   /* processed memory [B,Tin,A], [B,Tsub,A] */
-    size_t prea, preas;               /* attention-LSTM input pre-activations [B,T,4*Ha] */
-    size_t ga, gas;                   /* activated gates i,f,g,o [B,T,4*Ha] */
-    size_t cna, cnas, ca, cas;        /* cell before / after dropout [B,T,Ha] */
-    size_t din;                       /* [B,T, 2*Ha+2*E] = att_h | ctx | att_h_sub | ctx_sub */
+    size_t prea, preas;               /* attention-LSTM input pre-activations [T,B,4*Ha] */
+    size_t ga, gas;                   /* activated gates i,f,g,o [T,B,4*Ha] */
+    size_t cna, cnas, ca, cas;        /* cell before / after dropout [T,B,Ha] */
+    size_t din;                       /* [T,B, 2*Ha+2*E] = att_h | ctx | att_h_sub | ctx_sub */
     size_t psel, psels;               /* SMA p_t [B,T,Tin], [B,T,Tsub] */
     size_t wcum, wcums;               /* LSA cumulative weights per step [B,T,Tin], [B,T,Tsub] */
-    size_t pred, gd, cnd, cd;         /* decoder LSTM: pre-activations, gates [B,T,4*Hd], cells [B,T,Hd] */
-    size_t dout;                      /* [B,T, Hd+2*E] = dec_h | ctx | ctx_sub */
-    size_t qs, qss;                   /* processed query per step [B,T,A] */
+    size_t pred, gd, cnd, cd;         /* decoder LSTM: pre-activations, gates [T,B,4*Hd], cells [T,B,Hd] */
+    size_t dout;                      /* [T,B, Hd+2*E] = dec_h | ctx | ctx_sub */
+    size_t qs, qss;                   /* processed query per step [T,B,A] */
     size_t qpart;                     /* per-step scratch [2][Ha/8][B][A] */
     size_t gemm_ws; size_t gemm_ws_floats;
 } t2_decoder_layout;
@@ -129,7 +131,7 @@ typedef struct t2_decoder_grads {
 typedef struct t2_decoder_bwd_layout {
     size_t total_floats;
     size_t ddout, ddin, dgd, dga, dgas, dctx, dctxs, dq, dqs, dv, dvs, dpm, dpms, carry, carrys;
-    size_t dcd, dca, dcas, partd, parta, dp2, dp2s, dp1, colsum_ws, gemm_ws, gemm_ws_floats;
+    size_t dcd, dca, dcas, partd, parta, dp2, dp2s, dp1, dmel_t, dgate_t, colsum_ws, gemm_ws, gemm_ws_floats;
 } t2_decoder_bwd_layout;
 int t2_decoder_bwd_layout_query(const t2_dims* dims, int B, int T, int Tin, int Tsub, t2_decoder_bwd_layout* out);
 typedef struct t2_decoder_bwd_args {

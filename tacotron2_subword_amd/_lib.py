@@ -86,7 +86,7 @@ class DecoderGrads(C.Structure):
 
 _BWD_LAYOUT_FIELDS = ["total_floats", "ddout", "ddin", "dgd", "dga", "dgas", "dctx", "dctxs", "dq", "dqs", "dv", "dvs",
                       "dpm", "dpms", "carry", "carrys", "dcd", "dca", "dcas", "partd", "parta", "dp2", "dp2s", "dp1",
-                      "colsum_ws", "gemm_ws", "gemm_ws_floats"]
+                      "dmel_t", "dgate_t", "colsum_ws", "gemm_ws", "gemm_ws_floats"]
 
 
 class DecoderBwdLayout(C.Structure):

@@ -17,7 +17,7 @@ namespace t2 {
 
 namespace {
 
-constexpr int NT = 256;
+constexpr int NT = 1024;     // 16 waves: the kernels are latency-bound row streams, more waves = more loads in flight
 
 __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
     // red: >= 4 floats of LDS; result broadcast to all threads
@@ -43,26 +43,27 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
     float* e = vs + A;               // [Tp]
     float* ap = e + Tp;              // [Tp]
     float* an = ap + Tp;             // [Tp]
-    float* red = an + Tp;            // [NT]
-    float* cred = red + NT;          // [nh*E]
+    float* red = an + Tp;            // [4*NT]  (query partial groups: (NT/(A/4)) * A floats)
+    float* cred = red + 4 * NT;      // [nh*E]
     const int nd = E / 4, nh = NT / nd;
     float* lsa = cred + nh * E;      // LSA only: convw[F*2*Kc] dense[A*(F+1)] loc[Tin*(F+1)] wpad[2][Tin+Kc-1]
 
     // ---- query: direct, or ordered sum of the partials emitted by lstm_step_fwd
     if (st.qpart) {
-        const int nq = NT / A;       // A <= NT checked on the host
-        const int h = tid / A, a = tid % A;
-        if (h < nq) {
-            float sum = 0.f;
-            const float* p = st.qpart + (long)b * A + a;
-            const long ps = (long)d.B * A;
-            for (int i = h; i < st.nparts; i += nq) sum += p[(long)i * ps];
-            red[h * A + a] = sum;
-        }
+        // groups of A/4 lanes read one partial row (16 B per lane); NT/(A/4) rows in flight per pass
+        const int a4n = A / 4, ng = NT / a4n;
+        const int pg = tid / a4n, a4 = (tid % a4n) * 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* p = st.qpart + (long)b * A + a4;
+        const long ps = (long)d.B * A;
+#pragma unroll 4
+        for (int i = pg; i < st.nparts; i += ng) acc += *reinterpret_cast<const f32x4*>(p + (long)i * ps);
+        *reinterpret_cast<f32x4*>(red + pg * A + a4) = acc;
         __syncthreads();
         if (tid < A) {
             float sum = 0.f;
-            for (int h2 = 0; h2 < nq; ++h2) sum += red[h2 * A + tid];
+            const int used = st.nparts < ng ? st.nparts : ng;
+            for (int h2 = 0; h2 < used; ++h2) sum += red[h2 * A + tid];
             q[tid] = sum;
             if (st.q_out) st.q_out[(long)b * st.ldq_out + tid] = sum;
         }
@@ -177,18 +178,22 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
     }
     __syncthreads();
 
-    // ---- context: nh groups of nd lanes, each lane 4 channels; group h takes j = h, h+nh, ...
+    // ---- context: nh groups of nd lanes, each lane 4 channels; group h takes j = jlo+h, jlo+h+nh, ...
+    // Only the band [jlo, jhi) of non-zero weights is read (an SMA alignment is a narrow band that
+    // starts one-hot; exact zeros contribute nothing), with no branch inside the unrolled loop.
     {
+        int lo = Tin, hi = 0;
+        for (int j = tid; j < Tin; j += NT) if (an[j] != 0.f) { lo = min(lo, j); hi = max(hi, j + 1); }
+        lo = -(int)block_reduce(-(float)lo, red, true);
+        hi = (int)block_reduce((float)hi, red, true);
         const int h = tid / nd, dd = (tid % nd) * 4;
         if (h < nh) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const float* mp = st.memory + (long)b * Tin * E + dd;
-            for (int j = h; j < Tin; j += nh) {
-                const float a = an[j];
-                if (a != 0.f) {
-                    const f32x4 mv = *reinterpret_cast<const f32x4*>(mp + (long)j * E);
-                    acc += a * mv;
-                }
+#pragma unroll 4
+            for (int j = lo + h; j < hi; j += nh) {
+                const f32x4 mv = *reinterpret_cast<const f32x4*>(mp + (long)j * E);
+                acc += an[j] * mv;
             }
             *reinterpret_cast<f32x4*>(cred + h * E + dd) = acc;
         }
@@ -212,7 +217,9 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
 //   dq_k   = sum_j dpre_jk ; dv_k += sum_j de_j u_jk ; dpm_jk += dpre_jk
 //   carry_j <- g_j p_j + g_{j+1} (1 - p_j)                            gradient on a_{t-1}[j]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void attention_step_bwd_kernel(AttnBwdDesc d) {
+constexpr int NTB = 512;     // backward keeps per-lane dq/dv accumulators: 8 waves leave it 256 VGPRs
+
+__global__ __launch_bounds__(NTB) void attention_step_bwd_kernel(AttnBwdDesc d) {
     const AttnBwdStream& st = d.st[blockIdx.y];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int Tin = st.Tin, A = d.A, E = d.E;
@@ -224,9 +231,9 @@ __global__ __launch_bounds__(NT) void attention_step_bwd_kernel(AttnBwdDesc d) {
     float* g = vs + A;               // [Tp + 1]  (g[Tin] = 0)
     float* de = g + Tp + 4;          // [Tp]
     float* ps = de + Tp;             // [Tp]
-    float* red = ps + Tp;            // [16][A] x 2 (dq, dv partials of the 16 position groups)
+    float* red = ps + Tp;            // [NT/16][A] x 2 (dq, dv partials of the NT/16 position groups)
 
-    for (int c = tid; c < E; c += NT) {
+    for (int c = tid; c < E; c += NTB) {
         float v = 0.f;
 #pragma unroll
         for (int i = 0; i < 3; ++i) if (st.dctx[i]) v += st.dctx[i][(long)b * st.lddctx[i] + c];
@@ -239,15 +246,16 @@ __global__ __launch_bounds__(NT) void attention_step_bwd_kernel(AttnBwdDesc d) {
         dctx[c] = v;
         st.dctx_out[(long)b * st.lddctx_out + c] = v;
     }
-    for (int a = tid; a < A; a += NT) { q[a] = st.q[(long)b * st.ldq + a]; vs[a] = st.v[a]; }
-    for (int j = tid; j < Tin; j += NT) ps[j] = st.p[(long)b * st.ldp + j];
+    for (int a = tid; a < A; a += NTB) { q[a] = st.q[(long)b * st.ldq + a]; vs[a] = st.v[a]; }
+    for (int j = tid; j < Tin; j += NTB) ps[j] = st.p[(long)b * st.ldp + j];
     if (tid == 0) g[Tin] = 0.f;
     __syncthreads();
 
     // g_j: one wave per position, lanes stride the E channels 16 B at a time
     {
         const int wave = tid >> 6, lane = tid & 63;
-        for (int j = wave; j < Tin; j += NT / 64) {
+#pragma unroll 2
+        for (int j = wave; j < Tin; j += NTB / 64) {
             const float* mr = st.memory + ((long)b * Tin + j) * E;
             float sum = 0.f;
             for (int c = lane * 4; c < E; c += 256) {
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(NT) void attention_step_bwd_kernel(AttnBwdDesc d) {
         }
     }
     __syncthreads();
-    for (int j = tid; j < Tin; j += NT) {
+    for (int j = tid; j < Tin; j += NTB) {
         const float ap = st.a_prev ? st.a_prev[(long)b * st.lda_prev + j] : (j == 0 ? 1.f : 0.f);
         const float p = ps[j];
         const float gj = g[j], gn = g[j + 1];
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(NT) void attention_step_bwd_kernel(AttnBwdDesc d) {
         for (int i = 0; i < MAXI; ++i)
 #pragma unroll
             for (int c = 0; c < 4; ++c) { dq[i][c] = 0.f; dv[i][c] = 0.f; }
-        for (int j = gid; j < Tin; j += NT / 16) {
+        for (int j = gid; j < Tin; j += NTB / 16) {
             const float dej = de[j];
             const float* pmr = st.pm + ((long)b * Tin + j) * A;
             float* dpr = st.dpm_acc + ((long)b * Tin + j) * A;
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(NT) void attention_step_bwd_kernel(AttnBwdDesc d) {
             }
         }
         float* rq = red;
-        float* rv = red + 16 * A;
+        float* rv = red + (NTB / 16) * A;
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {
             const int a = sub * 4 + 64 * i;
@@ -314,9 +322,9 @@ __global__ __launch_bounds__(NT) void attention_step_bwd_kernel(AttnBwdDesc d) {
             }
         }
         __syncthreads();
-        for (int a = tid; a < A; a += NT) {
+        for (int a = tid; a < A; a += NTB) {
             float sq = 0.f, sv = 0.f;
-            for (int k = 0; k < 16; ++k) { sq += rq[k * A + a]; sv += rv[k * A + a]; }
+            for (int k = 0; k < NTB / 16; ++k) { sq += rq[k * A + a]; sv += rv[k * A + a]; }
             st.dq_out[(long)b * st.lddq_out + a] = sq;
             float* dvp = st.dv_acc + (long)b * A + a;
             *dvp = (d.first ? 0.f : *dvp) + sv;
@@ -331,14 +339,14 @@ size_t attention_fwd_smem(const AttnStepDesc& d) {
     for (int i = 0; i < d.nstreams; ++i) Tmax = d.st[i].Tin > Tmax ? d.st[i].Tin : Tmax;
     const int Tp = (Tmax + 3) & ~3;
     const int nh = NT / (d.E / 4);
-    size_t n = 2 * d.A + 3 * Tp + NT + (size_t)nh * d.E;
+    size_t n = 2 * d.A + 3 * Tp + 4 * NT + (size_t)nh * d.E;
     if (d.kind == 1) n += (size_t)d.F * 2 * d.Kc + (size_t)d.A * (d.F + 1) + (size_t)Tmax * (d.F + 1) + 2 * (size_t)(Tmax + d.Kc - 1);
     return n * sizeof(float);
 }
 
 int attention_step_fwd(const AttnStepDesc& d, hipStream_t s) {
     T2_REQUIRE(d.nstreams >= 1 && d.nstreams <= 2, "attention_step: nstreams=%d", d.nstreams);
-    T2_REQUIRE(d.A % 4 == 0 && d.A <= NT, "attention_step: attention_dim %d must be a multiple of 4 and <= %d", d.A, NT);
+    T2_REQUIRE(d.A % 4 == 0 && d.A <= 256 && NT % (d.A / 4) == 0, "attention_step: attention_dim %d must be a multiple of 4 dividing %d, <= 256", d.A, 4 * NT);
     T2_REQUIRE(d.E % 4 == 0 && d.E / 4 <= NT && NT % (d.E / 4) == 0, "attention_step: encoder dim %d unsupported", d.E);
     T2_REQUIRE(d.kind == 0 || (d.Kc % 2 == 1 && d.F >= 1), "attention_step: bad location layer F=%d Kc=%d", d.F, d.Kc);
     for (int i = 0; i < d.nstreams; ++i)
@@ -361,13 +369,13 @@ int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s) {
     int Tmax = 0;
     for (int i = 0; i < d.nstreams; ++i) Tmax = d.st[i].Tin > Tmax ? d.st[i].Tin : Tmax;
     const int Tp = (Tmax + 3) & ~3;
-    const size_t smem = ((size_t)d.E + 2 * d.A + (Tp + 4) + 2 * Tp + 32 * (size_t)d.A) * sizeof(float);
+    const size_t smem = ((size_t)d.E + 2 * d.A + (Tp + 4) + 2 * Tp + 2 * (NTB / 16) * (size_t)d.A) * sizeof(float);
     T2_REQUIRE(smem <= 160 * 1024, "attention_bwd: T_in too long for LDS (%zu bytes)", smem);
     if (smem > 64 * 1024) {
         T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_step_bwd_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     }
-    hipLaunchKernelGGL(attention_step_bwd_kernel, dim3(d.B, d.nstreams), dim3(NT), smem, s, d);
+    hipLaunchKernelGGL(attention_step_bwd_kernel, dim3(d.B, d.nstreams), dim3(NTB), smem, s, d);
     T2_LAUNCH_CHECK();
     return 0;
 }

@@ -105,6 +105,7 @@ struct Dec {
     float* mel_out; float* gate_out; float* align; float* align_sub;
     bool training; bool prenet_dropout; bool teacher; uint64_t seed; hipStream_t s;
     float* P(size_t off) const { return ws + off; }
+    long R(int t) const { return (long)t * z.B; }      // first row of step t in a time-major [T,B,*] buffer
 };
 
 GemmDesc linear(const float* X, long ldx, const float* W, long ldw, float* Y, long ldy, int M, int N, int K) {
@@ -139,31 +140,30 @@ int att_lstm_step(const Dec& c, int t) {
     LstmStepDesc d{};
     d.nstreams = 2; d.B = z.B; d.H = z.Ha; d.seed = c.seed;
     d.drop_p = c.training ? c.d.p_att_dropout : 0.f;
-    const long ldD = (long)z.T * z.WD, ldH = (long)z.T * z.Ha, ldG = (long)z.T * 4 * z.Ha, ldP = (long)z.T * z.P;
+    float* DIN = c.P(L.din);
     for (int s = 0; s < 2; ++s) {
         LstmStream& st = d.st[s];
         const t2_lstm_weights& lw = s ? c.w.att_sub : c.w.att;
         const int hoff = s ? z.Ha + z.E : 0, coff = hoff + z.Ha;
-        float* DIN = c.P(L.din);
         int n = 0;
         if (!c.teacher) {
-            st.seg[n++] = LstmSeg{c.P(s ? L.p2s : L.p2) + (long)t * z.P, ldP, lw.w_ih, (long)(z.P + z.E), z.P};
+            st.seg[n++] = LstmSeg{c.P(s ? L.p2s : L.p2) + c.R(t) * z.P, (long)z.P, lw.w_ih, (long)(z.P + z.E), z.P};
             st.bias1 = lw.b_ih; st.bias2 = lw.b_hh;
         } else {
-            st.pre = c.P(s ? L.preas : L.prea) + (long)t * 4 * z.Ha; st.ldpre = ldG;
+            st.pre = c.P(s ? L.preas : L.prea) + c.R(t) * 4 * z.Ha; st.ldpre = 4 * z.Ha;
         }
         if (t > 0) {
-            st.seg[n++] = LstmSeg{DIN + (long)(t - 1) * z.WD + coff, ldD, lw.w_ih + z.P, (long)(z.P + z.E), z.E};
-            st.seg[n++] = LstmSeg{DIN + (long)(t - 1) * z.WD + hoff, ldD, lw.w_hh, (long)z.Ha, z.Ha};
-            st.c_prev = c.P(s ? L.cas : L.ca) + (long)(t - 1) * z.Ha; st.ldc_prev = ldH;
+            st.seg[n++] = LstmSeg{DIN + c.R(t - 1) * z.WD + coff, (long)z.WD, lw.w_ih + z.P, (long)(z.P + z.E), z.E};
+            st.seg[n++] = LstmSeg{DIN + c.R(t - 1) * z.WD + hoff, (long)z.WD, lw.w_hh, (long)z.Ha, z.Ha};
+            st.c_prev = c.P(s ? L.cas : L.ca) + c.R(t - 1) * z.Ha; st.ldc_prev = z.Ha;
         }
         st.nseg = n;
-        st.gates = c.P(s ? L.gas : L.ga) + (long)t * 4 * z.Ha; st.ldgates = ldG;
-        st.c_new = c.P(s ? L.cnas : L.cna) + (long)t * z.Ha; st.ldc_new = ldH;
-        st.c_out = c.P(s ? L.cas : L.ca) + (long)t * z.Ha; st.ldc_out = ldH;
-        st.h_out = DIN + (long)t * z.WD + hoff; st.ldh_out = ldD;
+        st.gates = c.P(s ? L.gas : L.ga) + c.R(t) * 4 * z.Ha; st.ldgates = 4 * z.Ha;
+        st.c_new = c.P(s ? L.cnas : L.cna) + c.R(t) * z.Ha; st.ldc_new = z.Ha;
+        st.c_out = c.P(s ? L.cas : L.ca) + c.R(t) * z.Ha; st.ldc_out = z.Ha;
+        st.h_out = DIN + c.R(t) * z.WD + hoff; st.ldh_out = z.WD;
         st.site_h = s ? T2_SITE_ATT_H_SUB : T2_SITE_ATT_H; st.site_c = s ? T2_SITE_ATT_C_SUB : T2_SITE_ATT_C;
-        st.idx_base = (uint32_t)t * z.Ha; st.idx_bstride = (uint32_t)z.T * z.Ha;
+        st.idx_base = (uint32_t)(c.R(t) * z.Ha); st.idx_bstride = (uint32_t)z.Ha;       // logical [T,B,Ha]
         st.wq = s ? c.w.attn_sub.wq : c.w.attn.wq; st.A = z.A;
         st.qpart = c.P(L.qpart) + (size_t)s * (z.Ha / 8) * z.B * z.A;
     }
@@ -178,16 +178,15 @@ int attention_step(const Dec& c, int t) {
     d.F = c.d.loc_filters; d.Kc = c.d.loc_kernel; d.seed = c.seed; d.first = t == 0;
     d.noise_std = (c.training && d.kind == T2_ATTN_SMA) ? 2.0f : 0.f;     // attention.py:315,346-348
     d.mask_value = -INFINITY;                                              // attention.py:37,306
-    const long ldD = (long)z.T * z.WD, ldO = (long)z.T * z.WO;
     for (int s = 0; s < 2; ++s) {
         AttnStream& st = d.st[s];
         const t2_attention_weights& aw = s ? c.w.attn_sub : c.w.attn;
         const int Tin = s ? z.Tsub : z.Tin;
-        float* al = s ? c.align_sub : c.align;
+        float* al = s ? c.align_sub : c.align;                       // [B,T,Tin]: the reference's output layout
         const long ldA = (long)z.T * Tin;
         st.Tin = Tin;
         st.qpart = c.P(L.qpart) + (size_t)s * (z.Ha / 8) * z.B * z.A; st.nparts = z.Ha / 8;
-        st.q_out = c.P(s ? L.qss : L.qs) + (long)t * z.A; st.ldq_out = (long)z.T * z.A;
+        st.q_out = c.P(s ? L.qss : L.qs) + c.R(t) * z.A; st.ldq_out = z.A;
         st.pm = c.P(s ? L.pms : L.pm); st.memory = s ? c.memory_sub : c.memory;
         st.lengths = s ? c.len_sub : c.len;
         st.a_prev = t > 0 ? al + (long)(t - 1) * Tin : nullptr; st.lda_prev = ldA;
@@ -199,11 +198,11 @@ int attention_step(const Dec& c, int t) {
             st.wcum_prev = t > 0 ? wc + (long)(t - 1) * Tin : nullptr; st.ldwcum_prev = ldA;
             st.wcum_out = wc + (long)t * Tin; st.ldwcum_out = ldA;
         }
-        st.ctx1 = c.P(L.din) + (long)t * z.WD + (s ? 2 * z.Ha + z.E : z.Ha); st.ldctx1 = ldD;
-        st.ctx2 = c.P(L.dout) + (long)t * z.WO + z.Hd + (s ? z.E : 0); st.ldctx2 = ldO;
+        st.ctx1 = c.P(L.din) + c.R(t) * z.WD + (s ? 2 * z.Ha + z.E : z.Ha); st.ldctx1 = z.WD;
+        st.ctx2 = c.P(L.dout) + c.R(t) * z.WO + z.Hd + (s ? z.E : 0); st.ldctx2 = z.WO;
         st.v = aw.v; st.loc_conv = aw.loc_conv; st.loc_dense = aw.loc_dense;
         st.site_noise = s ? T2_SITE_NOISE_SUB : T2_SITE_NOISE;
-        st.idx_base = (uint32_t)t * Tin; st.idx_bstride = (uint32_t)z.T * Tin;
+        st.idx_base = (uint32_t)(c.R(t) * Tin); st.idx_bstride = (uint32_t)Tin;          // logical [T,B,Tin]
     }
     ProfScope ps(PK_ATTN_FWD, c.s);
     return attention_step_fwd(d, c.s);
@@ -214,38 +213,39 @@ int dec_lstm_step(const Dec& c, int t) {
     LstmStepDesc d{};
     d.nstreams = 1; d.B = z.B; d.H = z.Hd; d.seed = c.seed;
     d.drop_p = c.training ? c.d.p_dec_dropout : 0.f;
-    const long ldO = (long)z.T * z.WO, ldH = (long)z.T * z.Hd, ldG = (long)z.T * 4 * z.Hd;
     LstmStream& st = d.st[0];
     int n = 0;
     if (!c.teacher) {
-        st.seg[n++] = LstmSeg{c.P(L.din) + (long)t * z.WD, (long)z.T * z.WD, c.w.dec.w_ih, (long)z.WD, z.WD};
+        st.seg[n++] = LstmSeg{c.P(L.din) + c.R(t) * z.WD, (long)z.WD, c.w.dec.w_ih, (long)z.WD, z.WD};
         st.bias1 = c.w.dec.b_ih; st.bias2 = c.w.dec.b_hh;
     } else {
-        st.pre = c.P(L.pred) + (long)t * 4 * z.Hd; st.ldpre = ldG;
+        st.pre = c.P(L.pred) + c.R(t) * 4 * z.Hd; st.ldpre = 4 * z.Hd;
     }
     if (t > 0) {
-        st.seg[n++] = LstmSeg{c.P(L.dout) + (long)(t - 1) * z.WO, ldO, c.w.dec.w_hh, (long)z.Hd, z.Hd};
-        st.c_prev = c.P(L.cd) + (long)(t - 1) * z.Hd; st.ldc_prev = ldH;
+        st.seg[n++] = LstmSeg{c.P(L.dout) + c.R(t - 1) * z.WO, (long)z.WO, c.w.dec.w_hh, (long)z.Hd, z.Hd};
+        st.c_prev = c.P(L.cd) + c.R(t - 1) * z.Hd; st.ldc_prev = z.Hd;
     }
     st.nseg = n;
-    st.gates = c.P(L.gd) + (long)t * 4 * z.Hd; st.ldgates = ldG;
-    st.c_new = c.P(L.cnd) + (long)t * z.Hd; st.ldc_new = ldH;
-    st.c_out = c.P(L.cd) + (long)t * z.Hd; st.ldc_out = ldH;
-    st.h_out = c.P(L.dout) + (long)t * z.WO; st.ldh_out = ldO;
+    st.gates = c.P(L.gd) + c.R(t) * 4 * z.Hd; st.ldgates = 4 * z.Hd;
+    st.c_new = c.P(L.cnd) + c.R(t) * z.Hd; st.ldc_new = z.Hd;
+    st.c_out = c.P(L.cd) + c.R(t) * z.Hd; st.ldc_out = z.Hd;
+    st.h_out = c.P(L.dout) + c.R(t) * z.WO; st.ldh_out = z.WO;
     st.site_h = T2_SITE_DEC_H; st.site_c = T2_SITE_DEC_C;
-    st.idx_base = (uint32_t)t * z.Hd; st.idx_bstride = (uint32_t)z.T * z.Hd;
+    st.idx_base = (uint32_t)(c.R(t) * z.Hd); st.idx_bstride = (uint32_t)z.Hd;             // logical [T,B,Hd]
     ProfScope ps(PK_LSTM_DEC_FWD, c.s);
     return lstm_step_fwd(d, c.s);
 }
 
-// mel / gate projection for rows t0 .. of the [B,T] grid (model.py:382-388)
-int projection(const Dec& c, const float* X, long ldx, int M, float* mel, long ldmel, float* gate, long ldgate) {
+// mel / gate projection (model.py:382-388); permute_tb: rows come time-major, outputs are [B,T,*]
+int projection(const Dec& c, const float* X, long ldx, int M, float* mel, long ldmel, float* gate, long ldgate, bool permute_tb) {
     const Sizes& z = c.z;
     GemmDesc g = linear(X, ldx, c.w.proj_w, z.WO, mel, ldmel, M, z.M, z.WO);
     g.bias1 = c.w.proj_b;
+    if (permute_tb) { g.crow_mod = z.B; g.crow_mul = z.T; }          // row (t,b) of DOUT -> row (b,t) of the output
     T2_TRY(gemm(g, c.s));
     GemmDesc h = linear(X, ldx, c.w.gate_w, z.WO, gate, ldgate, M, 1, z.WO);
     h.bias1 = c.w.gate_b;
+    if (permute_tb) { h.crow_mod = z.B; h.crow_mul = z.T; }
     return gemm(h, c.s);
 }
 
@@ -288,6 +288,7 @@ void bwd_layout_of(const t2_dims& d, const Sizes& z, t2_decoder_bwd_layout* L) {
     L->partd = take((size_t)ksd * z.B * z.Hd);
     L->parta = take((size_t)2 * ksa * z.B * (z.E + z.Ha));
     L->dp2 = take(BT * z.P); L->dp2s = take(BT * z.P); L->dp1 = take(BT * z.P);
+    L->dmel_t = take(BT * z.M); L->dgate_t = take(BT);
     L->colsum_ws = take((size_t)64 * 4 * (z.Ha > z.Hd ? z.Ha : z.Hd));
     L->gemm_ws_floats = (size_t)48 << 20;                     // 192 MiB of split-K scratch
     L->gemm_ws = take(L->gemm_ws_floats);
@@ -299,6 +300,7 @@ struct Bwd {
     Sizes z; t2_decoder_layout L; t2_decoder_bwd_layout BL; hipStream_t s;
     const float* W(size_t off) const { return a.ws + off; }
     float* S(size_t off) const { return a.bws + off; }
+    long R(int t) const { return (long)t * z.B; }
     float* gemm_ws() const { return a.bws + BL.gemm_ws; }
     size_t gemm_ws_bytes() const { return BL.gemm_ws_floats * sizeof(float); }
 };
@@ -328,15 +330,15 @@ int dec_bwd_step(const Bwd& c, int t) {
     p.nstreams = 1; p.B = z.B; p.H = z.Hd; p.seed = c.a.seed; p.first = t == z.T - 1;
     p.drop_p = c.a.training ? c.d.p_dec_dropout : 0.f;
     LstmBwdStream& st = p.st[0];
-    st.dh1 = c.S(c.BL.ddout) + (long)t * z.WO; st.lddh1 = (long)z.T * z.WO;
+    st.dh1 = c.S(c.BL.ddout) + c.R(t) * z.WO; st.lddh1 = z.WO;
     st.part = c.S(c.BL.partd); st.nparts = ks; st.part_stride = (long)z.B * z.Hd; st.ldpart = z.Hd; st.part_col = 0;
-    st.gates = c.W(c.L.gd) + (long)t * 4 * z.Hd; st.ldgates = (long)z.T * 4 * z.Hd;
-    st.c_new = c.W(c.L.cnd) + (long)t * z.Hd; st.ldc_new = (long)z.T * z.Hd;
-    if (t > 0) { st.c_prev = c.W(c.L.cd) + (long)(t - 1) * z.Hd; st.ldc_prev = (long)z.T * z.Hd; }
+    st.gates = c.W(c.L.gd) + c.R(t) * 4 * z.Hd; st.ldgates = 4 * z.Hd;
+    st.c_new = c.W(c.L.cnd) + c.R(t) * z.Hd; st.ldc_new = z.Hd;
+    if (t > 0) { st.c_prev = c.W(c.L.cd) + c.R(t - 1) * z.Hd; st.ldc_prev = z.Hd; }
     st.dc_state = c.S(c.BL.dcd);
-    st.dg = c.S(c.BL.dgd) + (long)t * 4 * z.Hd; st.lddg = (long)z.T * 4 * z.Hd;
+    st.dg = c.S(c.BL.dgd) + c.R(t) * 4 * z.Hd; st.lddg = 4 * z.Hd;
     st.site_h = T2_SITE_DEC_H; st.site_c = T2_SITE_DEC_C;
-    st.idx_base = (uint32_t)t * z.Hd; st.idx_bstride = (uint32_t)z.T * z.Hd;
+    st.idx_base = (uint32_t)(c.R(t) * z.Hd); st.idx_bstride = (uint32_t)z.Hd;
     { ProfScope ps(PK_LSTM_DEC_BWD_PW, c.s); T2_TRY(lstm_bwd_pointwise(p, c.s)); }
     if (t == 0) return 0;
     LstmBwdGemmDesc g{};
@@ -361,20 +363,20 @@ int att_bwd_step(const Bwd& c, int t) {
         const int Tin = s ? z.Tsub : z.Tin;
         const int hoff = s ? z.Ha + z.E : 0, coff = hoff + z.Ha;
         st.Tin = Tin;
-        st.dctx[0] = c.S(c.BL.ddout) + (long)t * z.WO + z.Hd + (s ? z.E : 0); st.lddctx[0] = (long)z.T * z.WO;
-        st.dctx[1] = c.S(c.BL.ddin) + (long)t * z.WD + coff; st.lddctx[1] = (long)z.T * z.WD;
+        st.dctx[0] = c.S(c.BL.ddout) + c.R(t) * z.WO + z.Hd + (s ? z.E : 0); st.lddctx[0] = z.WO;
+        st.dctx[1] = c.S(c.BL.ddin) + c.R(t) * z.WD + coff; st.lddctx[1] = z.WD;
         st.part = c.S(c.BL.parta) + (size_t)s * ks * z.B * NC; st.nparts = ks; st.part_stride = (long)z.B * NC; st.ldpart = NC; st.part_col = 0;
         const float* dal = s ? c.a.d_align_sub : c.a.d_align;
         if (dal) { st.dalign = dal + (long)t * Tin; st.lddalign = (long)z.T * Tin; }
-        st.q = c.W(s ? c.L.qss : c.L.qs) + (long)t * z.A; st.ldq = (long)z.T * z.A;
+        st.q = c.W(s ? c.L.qss : c.L.qs) + c.R(t) * z.A; st.ldq = z.A;
         st.pm = c.W(s ? c.L.pms : c.L.pm); st.memory = s ? c.a.memory_sub : c.a.memory;
         st.p = c.W(s ? c.L.psels : c.L.psel) + (long)t * Tin; st.ldp = (long)z.T * Tin;
         const float* al = s ? c.a.align_sub : c.a.align;
         if (t > 0) { st.a_prev = al + (long)(t - 1) * Tin; st.lda_prev = (long)z.T * Tin; }
         st.v = s ? c.w.attn_sub.v : c.w.attn.v;
         st.carry = c.S(s ? c.BL.carrys : c.BL.carry);
-        st.dctx_out = c.S(s ? c.BL.dctxs : c.BL.dctx) + (long)t * z.E; st.lddctx_out = (long)z.T * z.E;
-        st.dq_out = c.S(s ? c.BL.dqs : c.BL.dq) + (long)t * z.A; st.lddq_out = (long)z.T * z.A;
+        st.dctx_out = c.S(s ? c.BL.dctxs : c.BL.dctx) + c.R(t) * z.E; st.lddctx_out = z.E;
+        st.dq_out = c.S(s ? c.BL.dqs : c.BL.dq) + c.R(t) * z.A; st.lddq_out = z.A;
         st.dv_acc = c.S(s ? c.BL.dvs : c.BL.dv);
         st.dpm_acc = c.S(s ? c.BL.dpms : c.BL.dpm);
     }
@@ -386,17 +388,17 @@ int att_bwd_step(const Bwd& c, int t) {
     for (int s = 0; s < 2; ++s) {
         LstmBwdStream& st = p.st[s];
         const int hoff = s ? z.Ha + z.E : 0;
-        st.dh1 = c.S(c.BL.ddin) + (long)t * z.WD + hoff; st.lddh1 = (long)z.T * z.WD;
+        st.dh1 = c.S(c.BL.ddin) + c.R(t) * z.WD + hoff; st.lddh1 = z.WD;
         st.part = c.S(c.BL.parta) + (size_t)s * ks * z.B * NC; st.nparts = ks; st.part_stride = (long)z.B * NC; st.ldpart = NC; st.part_col = z.E;
-        st.dq = c.S(s ? c.BL.dqs : c.BL.dq) + (long)t * z.A; st.lddq = (long)z.T * z.A;
+        st.dq = c.S(s ? c.BL.dqs : c.BL.dq) + c.R(t) * z.A; st.lddq = z.A;
         st.wq = s ? c.w.attn_sub.wq : c.w.attn.wq; st.A = z.A;
-        st.gates = c.W(s ? c.L.gas : c.L.ga) + (long)t * 4 * z.Ha; st.ldgates = (long)z.T * 4 * z.Ha;
-        st.c_new = c.W(s ? c.L.cnas : c.L.cna) + (long)t * z.Ha; st.ldc_new = (long)z.T * z.Ha;
-        if (t > 0) { st.c_prev = c.W(s ? c.L.cas : c.L.ca) + (long)(t - 1) * z.Ha; st.ldc_prev = (long)z.T * z.Ha; }
+        st.gates = c.W(s ? c.L.gas : c.L.ga) + c.R(t) * 4 * z.Ha; st.ldgates = 4 * z.Ha;
+        st.c_new = c.W(s ? c.L.cnas : c.L.cna) + c.R(t) * z.Ha; st.ldc_new = z.Ha;
+        if (t > 0) { st.c_prev = c.W(s ? c.L.cas : c.L.ca) + c.R(t - 1) * z.Ha; st.ldc_prev = z.Ha; }
         st.dc_state = c.S(s ? c.BL.dcas : c.BL.dca);
-        st.dg = c.S(s ? c.BL.dgas : c.BL.dga) + (long)t * 4 * z.Ha; st.lddg = (long)z.T * 4 * z.Ha;
+        st.dg = c.S(s ? c.BL.dgas : c.BL.dga) + c.R(t) * 4 * z.Ha; st.lddg = 4 * z.Ha;
         st.site_h = s ? T2_SITE_ATT_H_SUB : T2_SITE_ATT_H; st.site_c = s ? T2_SITE_ATT_C_SUB : T2_SITE_ATT_C;
-        st.idx_base = (uint32_t)t * z.Ha; st.idx_bstride = (uint32_t)z.T * z.Ha;
+        st.idx_base = (uint32_t)(c.R(t) * z.Ha); st.idx_bstride = (uint32_t)z.Ha;
     }
     { ProfScope ps(PK_LSTM_ATT_BWD_PW, c.s); T2_TRY(lstm_bwd_pointwise(p, c.s)); }
     if (t == 0) return 0;
@@ -445,7 +447,7 @@ int t2_decoder_forward(const t2_dims* dims, const t2_decoder_weights* w, const t
 
     // teacher inputs and both prenets over all frames (model.py:407-413)
     T2_TRY(teacher_inputs(a->mels, c.P(L.x), z.B, z.M, z.T, c.s));
-    T2_TRY(prenet(c, false, c.P(L.x), z.M, BT, c.P(L.p1), c.P(L.p2), z.P, 0, 0));
+    T2_TRY(prenet(c, false, c.P(L.x), z.M, BT, c.P(L.p1), c.P(L.p2), z.P, 0, 0));      // rows time-major: (t,b)
     T2_TRY(prenet(c, true, c.P(L.x), z.M, BT, c.P(L.p1s), c.P(L.p2s), z.P, 0, 0));
     T2_TRY(processed_memory(c));                                    // model.py:258,261
     // hoisted input half of both attention LSTMs:  P2 . W_ih[:, :P]^T + b_ih + b_hh
@@ -469,7 +471,7 @@ int t2_decoder_forward(const t2_dims* dims, const t2_decoder_weights* w, const t
     // serial loop B: decoder LSTM recurrence
     for (int t = 0; t < z.T; ++t) T2_TRY(dec_lstm_step(c, t));
     // projections over all frames
-    return projection(c, c.P(L.dout), z.WO, BT, a->mel_out, z.M, a->gate_out, 1);
+    return projection(c, c.P(L.dout), z.WO, BT, a->mel_out, z.M, a->gate_out, 1, true);
 }
 
 
@@ -493,17 +495,21 @@ int t2_decoder_backward(const t2_dims* dims, const t2_decoder_weights* w, const 
     const int BT = z.B * z.T;
     float* cws = c.S(BL.colsum_ws);
 
+    // ---- incoming gradients arrive in the output layout [B,T,*]; everything inside is time-major
+    float* dmel = c.S(BL.dmel_t); float* dgate = c.S(BL.dgate_t);
+    T2_TRY(permute_rows(a->d_mel, dmel, z.B, z.T, z.M, c.s));
+    T2_TRY(permute_rows(a->d_gate, dgate, z.B, z.T, 1, c.s));
     // ---- projections (model.py:382-388): dDOUT = d_mel . Wproj + d_gate . Wgate ; weight gradients
     {
-        GemmDesc x = matmul_nn(a->d_mel, z.M, w->proj_w, z.WO, c.S(BL.ddout), z.WO, BT, z.WO, z.M);
+        GemmDesc x = matmul_nn(dmel, z.M, w->proj_w, z.WO, c.S(BL.ddout), z.WO, BT, z.WO, z.M);
         T2_TRY(gemm(x, c.s));
-        GemmDesc y = matmul_nn(a->d_gate, 1, w->gate_w, z.WO, c.S(BL.ddout), z.WO, BT, z.WO, 1);
+        GemmDesc y = matmul_nn(dgate, 1, w->gate_w, z.WO, c.S(BL.ddout), z.WO, BT, z.WO, 1);
         y.beta = 1.f;
         T2_TRY(gemm(y, c.s));
-        T2_TRY(gemm(matmul_tn(c, a->d_mel, z.M, c.W(L.dout), z.WO, g->proj_w, z.WO, z.M, z.WO, BT), c.s));
-        T2_TRY(gemm(matmul_tn(c, a->d_gate, 1, c.W(L.dout), z.WO, g->gate_w, z.WO, 1, z.WO, BT), c.s));
-        T2_TRY(colsum(a->d_mel, z.M, BT, z.M, g->proj_b, nullptr, cws, c.s));
-        T2_TRY(colsum(a->d_gate, 1, BT, 1, g->gate_b, nullptr, cws, c.s));
+        T2_TRY(gemm(matmul_tn(c, dmel, z.M, c.W(L.dout), z.WO, g->proj_w, z.WO, z.M, z.WO, BT), c.s));
+        T2_TRY(gemm(matmul_tn(c, dgate, 1, c.W(L.dout), z.WO, g->gate_w, z.WO, 1, z.WO, BT), c.s));
+        T2_TRY(colsum(dmel, z.M, BT, z.M, g->proj_b, nullptr, cws, c.s));
+        T2_TRY(colsum(dgate, 1, BT, 1, g->gate_b, nullptr, cws, c.s));
     }
     // ---- decoder LSTM, reverse time
     for (int t = z.T - 1; t >= 0; --t) T2_TRY(dec_bwd_step(c, t));
@@ -512,9 +518,9 @@ int t2_decoder_backward(const t2_dims* dims, const t2_decoder_weights* w, const 
         // input half: dDIN = dG . W_ih ; dW_ih = dG^T . DIN ; recurrent half: dW_hh = dG^T . dec_h(t-1)
         T2_TRY(gemm(matmul_nn(DG, 4 * z.Hd, w->dec.w_ih, z.WD, c.S(BL.ddin), z.WD, BT, z.WD, 4 * z.Hd), c.s));
         T2_TRY(gemm(matmul_tn(c, DG, 4 * z.Hd, c.W(L.din), z.WD, g->dec.w_ih, z.WD, 4 * z.Hd, z.WD, BT), c.s));
-        GemmDesc hh = matmul_tn(c, DG, 4 * z.Hd, c.W(L.dout) - z.WO, z.WO, g->dec.w_hh, z.Hd, 4 * z.Hd, z.Hd, BT);
-        hh.kmask_period = z.T; hh.kmask_phase = 0;
-        T2_TRY(gemm(hh, c.s));
+        // h(t-1) pairs with dG(t): drop the first step's rows of dG and the last step's rows of dec_h
+        if (z.T > 1) T2_TRY(gemm(matmul_tn(c, DG + (long)z.B * 4 * z.Hd, 4 * z.Hd, c.W(L.dout), z.WO, g->dec.w_hh, z.Hd, 4 * z.Hd, z.Hd, BT - z.B), c.s));
+        else T2_TRY(fill_f32(g->dec.w_hh, 0.f, (size_t)4 * z.Hd * z.Hd, c.s));
         T2_TRY(colsum(DG, 4 * z.Hd, BT, 4 * z.Hd, g->dec.b_ih, g->dec.b_hh, cws, c.s));
     }
     // ---- attention LSTMs + attention, reverse time
@@ -533,12 +539,16 @@ int t2_decoder_backward(const t2_dims* dims, const t2_decoder_weights* w, const 
         const long ldw = z.P + z.E;
         // LSTM weights: W_ih = [prenet part | ctx part], W_hh, biases
         T2_TRY(gemm(matmul_tn(c, DG, 4 * z.Ha, P2, z.P, lg.w_ih, ldw, 4 * z.Ha, z.P, BT), c.s));
-        GemmDesc wc = matmul_tn(c, DG, 4 * z.Ha, DIN - z.WD + coff, z.WD, lg.w_ih + z.P, ldw, 4 * z.Ha, z.E, BT);
-        wc.kmask_period = z.T; wc.kmask_phase = 0;
-        T2_TRY(gemm(wc, c.s));
-        GemmDesc wh = matmul_tn(c, DG, 4 * z.Ha, DIN - z.WD + hoff, z.WD, lg.w_hh, z.Ha, 4 * z.Ha, z.Ha, BT);
-        wh.kmask_period = z.T; wh.kmask_phase = 0;
-        T2_TRY(gemm(wh, c.s));
+        if (z.T > 1) {
+            const float* DG1 = DG + (long)z.B * 4 * z.Ha;             // rows of steps 1..T-1 pair with ctx/h of steps 0..T-2
+            T2_TRY(gemm(matmul_tn(c, DG1, 4 * z.Ha, DIN + coff, z.WD, lg.w_ih + z.P, ldw, 4 * z.Ha, z.E, BT - z.B), c.s));
+            T2_TRY(gemm(matmul_tn(c, DG1, 4 * z.Ha, DIN + hoff, z.WD, lg.w_hh, z.Ha, 4 * z.Ha, z.Ha, BT - z.B), c.s));
+        } else {
+            GemmDesc zc = matmul_tn(c, DG, 4 * z.Ha, DIN + coff, z.WD, lg.w_ih + z.P, ldw, 4 * z.Ha, z.E, BT);
+            zc.alpha = 0.f;
+            T2_TRY(gemm(zc, c.s));
+            T2_TRY(fill_f32(lg.w_hh, 0.f, (size_t)4 * z.Ha * z.Ha, c.s));
+        }
         T2_TRY(colsum(DG, 4 * z.Ha, BT, 4 * z.Ha, lg.b_ih, lg.b_hh, cws, c.s));
         // prenet (model.py:13-24): dP2 = dG . W_ih[:, :P] ; through ReLU+dropout ; layer 2 ; layer 1
         const float scale = a->prenet_dropout ? 1.0f / (1.0f - dims->p_prenet_dropout) : 1.0f;
@@ -559,7 +569,7 @@ int t2_decoder_backward(const t2_dims* dims, const t2_decoder_weights* w, const 
         T2_TRY(gemm(matmul_nn(DPM, z.A, aw.wm, z.E, dmem, z.E, z.B * Tin, z.E, z.A), c.s));
         GemmDesc dm = gemm_desc();
         dm.A = s ? a->align_sub : a->align; dm.sam = 1; dm.sak = Tin; dm.bsA = (long)z.T * Tin;
-        dm.B = c.S(s ? BL.dctxs : BL.dctx); dm.sbk = z.E; dm.sbn = 1; dm.bsB = (long)z.T * z.E;
+        dm.B = c.S(s ? BL.dctxs : BL.dctx); dm.sbk = (long)z.B * z.E; dm.sbn = 1; dm.bsB = z.E;     // dctx is [T,B,E]
         dm.C = dmem; dm.ldc = z.E; dm.bsC = (long)Tin * z.E;
         dm.M = Tin; dm.N = z.E; dm.K = z.T; dm.batch = z.B; dm.beta = 1.f;
         T2_TRY(gemm(dm, c.s));
@@ -589,14 +599,14 @@ int t2_decoder_infer(const t2_dims* dims, const t2_decoder_weights* w, const t2_
         // prenet of the previous output frame (model.py:449-450,470-471)
         const float* X = t == 0 ? c.P(L.x) : a->mel_out + (long)(t - 1) * z.M;
         const long ldx = t == 0 ? z.M : (long)T * z.M;
-        const uint32_t base = (uint32_t)t * z.P, mstride = (uint32_t)T * z.P;
-        T2_TRY(prenet(c, false, X, ldx, z.B, c.P(L.p1) + (long)t * z.P, c.P(L.p2) + (long)t * z.P, (long)T * z.P, base, mstride));
-        T2_TRY(prenet(c, true, X, ldx, z.B, c.P(L.p1s) + (long)t * z.P, c.P(L.p2s) + (long)t * z.P, (long)T * z.P, base, mstride));
+        const uint32_t base = (uint32_t)(c.R(t) * z.P), mstride = (uint32_t)z.P;
+        T2_TRY(prenet(c, false, X, ldx, z.B, c.P(L.p1) + c.R(t) * z.P, c.P(L.p2) + c.R(t) * z.P, z.P, base, mstride));
+        T2_TRY(prenet(c, true, X, ldx, z.B, c.P(L.p1s) + c.R(t) * z.P, c.P(L.p2s) + c.R(t) * z.P, z.P, base, mstride));
         T2_TRY(att_lstm_step(c, t));
         T2_TRY(attention_step(c, t));
         T2_TRY(dec_lstm_step(c, t));
-        T2_TRY(projection(c, c.P(L.dout) + (long)t * z.WO, (long)T * z.WO, z.B, a->mel_out + (long)t * z.M, (long)T * z.M,
-                          a->gate_out + t, T));
+        T2_TRY(projection(c, c.P(L.dout) + c.R(t) * z.WO, z.WO, z.B, a->mel_out + (long)t * z.M, (long)T * z.M,
+                          a->gate_out + t, T, false));
         hipLaunchKernelGGL(stop_check_kernel, dim3((z.B + 63) / 64), dim3(64), 0, c.s, a->gate_out, (long)T, t, z.B,
                            a->gate_threshold, a->stop_index, a->done_count);
         T2_LAUNCH_CHECK();

@@ -20,7 +20,7 @@ __global__ void rng_normal_kernel(RngKey k, uint32_t n, float* out) {
         out[i] = rng_normal(k, i);
 }
 
-// X[b,t,m] = t == 0 ? 0 : mel[b,m,t-1]      (Decoder.forward, model.py:407-411)
+// X[t,b,m] = t == 0 ? 0 : mel[b,m,t-1]      (Decoder.forward, model.py:407-411), time-major output
 __global__ void teacher_inputs_kernel(const float* __restrict__ mel, float* __restrict__ X, int B, int M, int T) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z, t0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
@@ -34,7 +34,7 @@ __global__ void teacher_inputs_kernel(const float* __restrict__ mel, float* __re
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int t = t0 + i, m = m0 + tx;
-        if (t < T && m < M) X[((long)b * T + t) * M + m] = tile[tx][i];
+        if (t < T && m < M) X[((long)t * B + b) * M + m] = tile[tx][i];
     }
 }
 
@@ -66,6 +66,16 @@ __global__ void mask_bt_kernel(float* x, int B, int T, const int* __restrict__ l
 
 __global__ void fill_kernel(float* p, float v, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ void permute_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int R1, int R2, int W) {
+    const size_t n = (size_t)R1 * R2 * W;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        const size_t r = i / W;
+        const int r1 = (int)(r % R1), r2 = (int)(r / R1);          // output row index = r2*R1 + r1
+        out[i] = in[((size_t)r1 * R2 + r2) * W + w];
+    }
 }
 
 __global__ void relu_drop_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* dz, float scale, size_t n) {
@@ -104,6 +114,12 @@ __global__ void batch_sum_kernel(const float* __restrict__ X, int B, int n, floa
 
 }  // namespace
 
+int permute_rows(const float* in, float* out, int R1, int R2, int W, hipStream_t s) {
+    const size_t n = (size_t)R1 * R2 * W;
+    hipLaunchKernelGGL(permute_rows_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, R1, R2, W);
+    T2_LAUNCH_CHECK();
+    return 0;
+}
 int relu_drop_bwd(const float* dy, const float* y, float* dz, float scale, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, dy, y, dz, scale, n);
     T2_LAUNCH_CHECK();

@@ -37,7 +37,8 @@ __device__ __forceinline__ void epilogue_store(const GemmDesc& d, float* C, int 
         uint32_t idx = d.drop_base + (uint32_t)m * d.drop_mstride + (uint32_t)n;
         v = rng_keep(key, idx, d.drop_p) ? v * (1.0f / (1.0f - d.drop_p)) : 0.f;
     }
-    float* p = C + (long)m * d.ldc + n;
+    const long mo = d.crow_mod ? (long)(m % d.crow_mod) * d.crow_mul + m / d.crow_mod : (long)m;
+    float* p = C + mo * d.ldc + n;
     if (d.beta != 0.f) v += d.beta * (*p);
     *p = v;
 }
@@ -45,7 +46,7 @@ __device__ __forceinline__ void epilogue_store(const GemmDesc& d, float* C, int 
 // Load one operand tile (R rows x BK) into registers.  KC: k is the contiguous stride.
 template <int R, bool KC>
 __device__ __forceinline__ void load_tile(const float* __restrict__ base, long srow, long sk, int row0, int nrows,
-                                          int k0, int kend, int vec, int kper, int kph, f32x4 (&regs)[R * 4 / 256]) {
+                                          int k0, int kend, int vec, f32x4 (&regs)[R * 4 / 256]) {
     constexpr int NQ = R * 4 / 256;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -55,10 +56,7 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ base, long s
             int row = row0 + (q >> 2), k = k0 + (q & 3) * 4;
             if (row < nrows) {
                 const float* p = base + (long)row * srow + k;
-                if (kper) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (k + j < kend && (k + j) % kper != kph) v[j] = p[j];
-                } else if (vec && k + 3 < kend) {
+                if (vec && k + 3 < kend) {
                     v = *reinterpret_cast<const f32x4*>(p);
                 } else {
 #pragma unroll
@@ -67,7 +65,7 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ base, long s
             }
         } else {
             int k = k0 + q / (R / 4), row = row0 + (q % (R / 4)) * 4;
-            if (k < kend && !(kper && k % kper == kph)) {
+            if (k < kend) {
                 const float* p = base + (long)k * sk + row;
                 if (vec && row + 3 < nrows) {
                     v = *reinterpret_cast<const f32x4*>(p);
@@ -129,8 +127,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK g) {
 
     f32x4 ra[BM * 4 / 256], rb[BN * 4 / 256];
     if (kbeg < kend) {
-        load_tile<BM, A_KC>(A, d.sam, d.sak, m0, d.M, kbeg, kend, g.avec, d.kmask_period, d.kmask_phase, ra);
-        load_tile<BN, B_KC>(B, d.sbn, d.sbk, n0, d.N, kbeg, kend, g.bvec, d.kmask_period, d.kmask_phase, rb);
+        load_tile<BM, A_KC>(A, d.sam, d.sak, m0, d.M, kbeg, kend, g.avec, ra);
+        load_tile<BN, B_KC>(B, d.sbn, d.sbk, n0, d.N, kbeg, kend, g.bvec, rb);
         store_tile<BM, A_KC>(As[0], ra);
         store_tile<BN, B_KC>(Bs[0], rb);
     }
@@ -139,8 +137,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK g) {
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = k0 + BK < kend;
         if (more) {
-            load_tile<BM, A_KC>(A, d.sam, d.sak, m0, d.M, k0 + BK, kend, g.avec, d.kmask_period, d.kmask_phase, ra);
-            load_tile<BN, B_KC>(B, d.sbn, d.sbk, n0, d.N, k0 + BK, kend, g.bvec, d.kmask_period, d.kmask_phase, rb);
+            load_tile<BM, A_KC>(A, d.sam, d.sak, m0, d.M, k0 + BK, kend, g.avec, ra);
+            load_tile<BN, B_KC>(B, d.sbn, d.sbk, n0, d.N, k0 + BK, kend, g.bvec, rb);
         }
         const float* as = As[cur] + wm * (BM / 2) + r;
         const float* bs = Bs[cur] + wn * (BN / 2) + r;

@@ -23,8 +23,8 @@ struct GemmDesc {
     uint32_t drop_base, drop_mstride;             // drop_mstride 0 -> N
     float* ws; size_t ws_bytes;                   // split-K scratch (nullable -> no split)
     int splitk;                                   // 0 = choose automatically
-    int kmask_period, kmask_phase;                // k rows with k % period == phase count as zero (0 = off):
-                                                  // lets a [B,T,*] operand be used shifted by one step
+    int crow_mod; long crow_mul;                  // output row = (m % crow_mod) * crow_mul + m / crow_mod (0 = identity):
+                                                  // writes time-major rows (t,b) in batch-major order (b,t) or back
 };
 inline GemmDesc gemm_desc() {
     GemmDesc d{}; d.batch = 1; d.alpha = 1.f; d.beta = 0.f; d.act = ACT_NONE; d.drop_p = 0.f; return d;
@@ -127,12 +127,14 @@ int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s);
 // ------------------------------------------------------------------ elementwise (elementwise.hip)
 int rng_keep_mask(uint64_t seed, uint32_t site, uint32_t n, float p, uint8_t* out, hipStream_t s);
 int rng_normal(uint64_t seed, uint32_t site, uint32_t n, float* out, hipStream_t s);
-// X[b,t,:] = (t == 0) ? 0 : mel[b,:,t-1]   (go frame + teacher forcing shift; mel is [B,M,T])
+// X[t,b,:] = (t == 0) ? 0 : mel[b,:,t-1]   (go frame + teacher forcing shift; mel is [B,M,T])
 int teacher_inputs(const float* mel, float* X, int B, int M, int T, hipStream_t s);
 // out[b,c,t] = in[b,t,c] with optional padding fill for t >= lengths[b]
 int transpose_btc_to_bct(const float* in, float* out, int B, int T, int C, const int* lengths, float fill, hipStream_t s);
 int mask_bt(float* x, int B, int T, const int* lengths, float fill, hipStream_t s);
 int fill_f32(float* p, float v, size_t n, hipStream_t s);
+// out[r2, r1, :] = in[r1, r2, :]   ([R1,R2,W] -> [R2,R1,W])
+int permute_rows(const float* in, float* out, int R1, int R2, int W, hipStream_t s);
 // dz = dy * (y > 0 ? scale : 0)   (ReLU + dropout backward from the saved output; in place allowed)
 int relu_drop_bwd(const float* dy, const float* y, float* dz, float scale, size_t n, hipStream_t s);
 // out[n] = sum_m X[m*ld + n]  (bias gradients; two fixed-order stages, scratch >= 64*N floats); out2 optional copy

@@ -42,6 +42,30 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_fwd_kernel(LstmStepDesc d) 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
 
+    // The pointwise tail needs pre[b, g*H+u] (streamed once from HBM) and c_prev: request them
+    // now so that their latency hides under the GEMM instead of being paid after it.
+    constexpr bool kPrefetch = MT <= 4;
+    float pre_v[kPrefetch ? MT : 1][4];
+    float cp_v[kPrefetch ? MT : 1];
+    if (kPrefetch && threadIdx.x < 32 * HU) {
+        const int bl = threadIdx.x >> 3, u = u0 + (threadIdx.x & 7);
+#pragma unroll
+        for (int m = 0; m < (kPrefetch ? MT : 1); ++m) {
+            const int b = m * 32 + bl;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v = 0.f;
+                if (b < B) {
+                    if (st.pre) v += st.pre[(long)b * st.ldpre + g * H + u];
+                    if (st.bias1) v += st.bias1[g * H + u];
+                    if (st.bias2) v += st.bias2[g * H + u];
+                }
+                pre_v[m][g] = v;
+            }
+            cp_v[m] = (b < B && st.c_prev) ? st.c_prev[(long)b * st.ldc_prev + u] : 0.f;
+        }
+    }
+
     for (int s = 0; s < st.nseg; ++s) {
         const LstmSeg sg = st.seg[s];
         const int kq = sg.k / NW;
@@ -54,20 +78,37 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_fwd_kernel(LstmStepDesc d) 
             xv[m] = row < B;
             xp[m] = sg.x + (long)(xv[m] ? row : 0) * sg.ldx + wave * kq + 4 * hk;
         }
-#pragma unroll 2
-        for (int k = 0; k < kq; k += 8) {
+        // Keep many 16-byte loads in flight per wave: at one workgroup per CU the loop is bound by
+        // L2/MALL latency, not by the MFMA rate, unless ~100 KB per CU are outstanding.  So the
+        // operands of U k-steps are requested first and only then fed to the matrix core.
+        constexpr int U = MT <= 2 ? 8 : (MT <= 4 ? 4 : 1);
+        int k = 0;
+        for (; k + 8 * U <= kq; k += 8 * U) {
+            f32x4 w4[U], x4[U][MT];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                w4[u] = *reinterpret_cast<const f32x4*>(wp + k + 8 * u);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) x4[u][m] = *reinterpret_cast<const f32x4*>(xp[m] + k + 8 * u);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // all U*(1+MT) loads are issued before the first MFMA
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[m] ? x4[u][m][j] : 0.f, w4[u][j], acc[m], 0, 0, 0);
+        }
+        for (; k < kq; k += 8) {
             const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + k);
-            f32x4 x4[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                x4[m] = *reinterpret_cast<const f32x4*>(xp[m] + k);
-                if (!xv[m]) x4[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 x4 = *reinterpret_cast<const f32x4*>(xp[m] + k);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[m] ? x4[j] : 0.f, w4[j], acc[m], 0, 0, 0);
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(x4[m][j], w4[j], acc[m], 0, 0, 0);
         }
     }
 
@@ -91,14 +132,18 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_fwd_kernel(LstmStepDesc d) 
                     float sum = 0.f;
 #pragma unroll
                     for (int w = 0; w < NW; ++w) sum += part[(w * 32 + bl) * PP + g * 8 + uu];
-                    if (st.pre) sum += st.pre[(long)b * st.ldpre + g * H + u];
-                    if (st.bias1) sum += st.bias1[g * H + u];
-                    if (st.bias2) sum += st.bias2[g * H + u];
+                    if (kPrefetch) {
+                        sum += pre_v[kPrefetch ? m : 0][g];
+                    } else {
+                        if (st.pre) sum += st.pre[(long)b * st.ldpre + g * H + u];
+                        if (st.bias1) sum += st.bias1[g * H + u];
+                        if (st.bias2) sum += st.bias2[g * H + u];
+                    }
                     g4[g] = sum;
                 }
                 const bool active = !st.lengths || st.t < st.lengths[b];
                 float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]), og = sigmoidf_(g4[3]);
-                const float cp = st.c_prev ? st.c_prev[(long)b * st.ldc_prev + u] : 0.f;
+                const float cp = kPrefetch ? cp_v[kPrefetch ? m : 0] : (st.c_prev ? st.c_prev[(long)b * st.ldc_prev + u] : 0.f);
                 float cn = fg * cp + ig * gg;
                 float hn = og * tanhf(cn);
                 if (!active) { ig = fg = gg = og = 0.f; cn = 0.f; hn = 0.f; }
@@ -166,6 +211,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(LstmBwdPointDes
         const float* q = st.dq + (long)b * st.lddq;
         const float* w = st.wq + u;
         float acc = 0.f;
+#pragma unroll 16
         for (int a = 0; a < st.A; ++a) acc += q[a] * w[(long)a * H];
         dh += acc;
     }
@@ -226,22 +272,38 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_gemm_kernel(LstmBwdGemmDesc 
         xv[m] = row < B;
         xp[m] = st.dg + (long)(xv[m] ? row : 0) * st.lddg + kbeg + 4 * hk;
     }
-#pragma unroll 2
-    for (int k = 0; k < kw; k += 8) {
+    constexpr int U = MT <= 2 ? 4 : 2;
+    int k = 0;
+    for (; k + 8 * U <= kw; k += 8 * U) {
+        float w4[U][4];
+        f32x4 x4[U][MT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w4[u][j] = wp[(long)(k + 8 * u + j) * sg.ldw];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) x4[u][m] = *reinterpret_cast<const f32x4*>(xp[m] + k + 8 * u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[m] ? x4[u][m][j] : 0.f, w4[u][j], acc[m], 0, 0, 0);
+    }
+    for (; k < kw; k += 8) {
         float w4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) w4[j] = wp[(long)(k + j) * sg.ldw];
-        f32x4 x4[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            x4[m] = *reinterpret_cast<const f32x4*>(xp[m] + k);
-            if (!xv[m]) x4[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 x4 = *reinterpret_cast<const f32x4*>(xp[m] + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[m] ? x4[j] : 0.f, w4[j], acc[m], 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(x4[m][j], w4[j], acc[m], 0, 0, 0);
     }
     float* out = st.part + (long)blockIdx.y * B * d.NC;
 #pragma unroll

@@ -52,12 +52,12 @@ def test_teacher_forced_vs_golden(env, att, name):
     assert maxabs(dp.align_sub.cpu(), g["align_bert"]) < TOL
     # recurrent state of the first / last step (nothing drifts over T steps)
     Ha, E, Hd = hp["attention_rnn_dim"], hp["encoder_embedding_dim"], hp["decoder_rnn_dim"]
-    din = dp.view("din", B, T, 2 * Ha + 2 * E).cpu()
-    assert maxabs(din[:, T - 1, :Ha], g["steplast_att_h"]) < TOL
-    assert maxabs(din[:, T - 1, Ha:Ha + E], g["steplast_ctx"]) < TOL
-    assert maxabs(din[:, 0, Ha + E:2 * Ha + E], g["step0_att_h_bert"]) < TOL
-    dout = dp.view("dout", B, T, Hd + 2 * E).cpu()
-    assert maxabs(dout[:, T - 1, :Hd], g["steplast_dec_h"]) < TOL
+    din = dp.view("din", T, B, 2 * Ha + 2 * E).cpu()             # time-major workspace
+    assert maxabs(din[T - 1, :, :Ha], g["steplast_att_h"]) < TOL
+    assert maxabs(din[T - 1, :, Ha:Ha + E], g["steplast_ctx"]) < TOL
+    assert maxabs(din[0, :, Ha + E:2 * Ha + E], g["step0_att_h_bert"]) < TOL
+    dout = dp.view("dout", T, B, Hd + 2 * E).cpu()
+    assert maxabs(dout[T - 1, :, :Hd], g["steplast_dec_h"]) < TOL
 
 
 @pytest.mark.parametrize("att", [SMA, LSA])
@@ -92,17 +92,17 @@ def test_teacher_forced_training_mode_replay(env, att):
     Pn, Ha, Hd = hp["prenet_dim"], hp["attention_rnn_dim"], hp["decoder_rnn_dim"]
     S = L.SITE
 
-    def km(site, p, *shape):        # HIP index order is [B,T,*]; the oracle wants [T,B,*]
-        return ops.rng_keep_mask(seed, S[site], int(np.prod(shape)), p).view(*shape).float().cpu().transpose(0, 1)
+    def km(site, p, *shape):        # HIP index order is [T,B,*], the oracle's layout
+        return ops.rng_keep_mask(seed, S[site], int(np.prod(shape)), p).view(*shape).float().cpu()
 
-    rnd = dict(prenet_keep=[km("PRENET1", 0.5, B, T, Pn), km("PRENET2", 0.5, B, T, Pn)],
-               prenet_bert_keep=[km("PRENET1_SUB", 0.5, B, T, Pn), km("PRENET2_SUB", 0.5, B, T, Pn)],
-               att_h_keep=km("ATT_H", 0.1, B, T, Ha), att_c_keep=km("ATT_C", 0.1, B, T, Ha),
-               att_h_bert_keep=km("ATT_H_SUB", 0.1, B, T, Ha), att_c_bert_keep=km("ATT_C_SUB", 0.1, B, T, Ha),
-               dec_h_keep=km("DEC_H", 0.1, B, T, Hd), dec_c_keep=km("DEC_C", 0.1, B, T, Hd))
+    rnd = dict(prenet_keep=[km("PRENET1", 0.5, T, B, Pn), km("PRENET2", 0.5, T, B, Pn)],
+               prenet_bert_keep=[km("PRENET1_SUB", 0.5, T, B, Pn), km("PRENET2_SUB", 0.5, T, B, Pn)],
+               att_h_keep=km("ATT_H", 0.1, T, B, Ha), att_c_keep=km("ATT_C", 0.1, T, B, Ha),
+               att_h_bert_keep=km("ATT_H_SUB", 0.1, T, B, Ha), att_c_bert_keep=km("ATT_C_SUB", 0.1, T, B, Ha),
+               dec_h_keep=km("DEC_H", 0.1, T, B, Hd), dec_c_keep=km("DEC_C", 0.1, T, B, Hd))
     if att == SMA:
-        rnd["sma_noise"] = ops.rng_normal(seed, S["NOISE"], B * T * Tin).view(B, T, Tin).cpu().transpose(0, 1)
-        rnd["sma_noise_bert"] = ops.rng_normal(seed, S["NOISE_SUB"], B * T * Tsub).view(B, T, Tsub).cpu().transpose(0, 1)
+        rnd["sma_noise"] = ops.rng_normal(seed, S["NOISE"], B * T * Tin).view(T, B, Tin).cpu()
+        rnd["sma_noise_bert"] = ops.rng_normal(seed, S["NOISE_SUB"], B * T * Tsub).view(T, B, Tsub).cpu()
     with torch.no_grad():
         mel, gate, al, alb = O.decoder_forward(mem, mem_sub, x[3], x[1], x[2], P, hp, rnd)
     dp = run_hip_decoder(env, P, hp, mem, mem_sub, x[1], x[2], x[3], training=True, prenet_dropout=True, seed=seed)

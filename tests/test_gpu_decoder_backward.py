@@ -27,15 +27,15 @@ def hip_rnd(ops, L, hp, seed, B, T, Tin, Tsub):
     S = L.SITE
 
     def km(site, p, *shape):
-        return ops.rng_keep_mask(seed, S[site], int(np.prod(shape)), p).view(*shape).float().cpu().transpose(0, 1)
+        return ops.rng_keep_mask(seed, S[site], int(np.prod(shape)), p).view(*shape).float().cpu()
 
-    return dict(prenet_keep=[km("PRENET1", 0.5, B, T, Pn), km("PRENET2", 0.5, B, T, Pn)],
-                prenet_bert_keep=[km("PRENET1_SUB", 0.5, B, T, Pn), km("PRENET2_SUB", 0.5, B, T, Pn)],
-                att_h_keep=km("ATT_H", 0.1, B, T, Ha), att_c_keep=km("ATT_C", 0.1, B, T, Ha),
-                att_h_bert_keep=km("ATT_H_SUB", 0.1, B, T, Ha), att_c_bert_keep=km("ATT_C_SUB", 0.1, B, T, Ha),
-                dec_h_keep=km("DEC_H", 0.1, B, T, Hd), dec_c_keep=km("DEC_C", 0.1, B, T, Hd),
-                sma_noise=ops.rng_normal(seed, S["NOISE"], B * T * Tin).view(B, T, Tin).cpu().transpose(0, 1),
-                sma_noise_bert=ops.rng_normal(seed, S["NOISE_SUB"], B * T * Tsub).view(B, T, Tsub).cpu().transpose(0, 1))
+    return dict(prenet_keep=[km("PRENET1", 0.5, T, B, Pn), km("PRENET2", 0.5, T, B, Pn)],
+                prenet_bert_keep=[km("PRENET1_SUB", 0.5, T, B, Pn), km("PRENET2_SUB", 0.5, T, B, Pn)],
+                att_h_keep=km("ATT_H", 0.1, T, B, Ha), att_c_keep=km("ATT_C", 0.1, T, B, Ha),
+                att_h_bert_keep=km("ATT_H_SUB", 0.1, T, B, Ha), att_c_bert_keep=km("ATT_C_SUB", 0.1, T, B, Ha),
+                dec_h_keep=km("DEC_H", 0.1, T, B, Hd), dec_c_keep=km("DEC_C", 0.1, T, B, Hd),
+                sma_noise=ops.rng_normal(seed, S["NOISE"], B * T * Tin).view(T, B, Tin).cpu(),
+                sma_noise_bert=ops.rng_normal(seed, S["NOISE_SUB"], B * T * Tsub).view(T, B, Tsub).cpu())
 
 
 @pytest.mark.parametrize("cfg", ["tiny_eval", "tiny_train", "tiny_b33", "default_train", "default_align"])

@@ -40,13 +40,21 @@ def test_forward_eval_vs_golden(att, name):
         assert maxabs(v, g[k]) < TOL, k
 
 
-def test_backward_eval_mode_vs_oracle_autograd():
-    """Whole-model gradients (encoders, converters, decoder, postnet) in eval mode (BN running
-    statistics, no dropout, no noise): HIP decoder backward inside torch autograd vs the oracle."""
+def test_backward_eval_mode_vs_oracle_autograd(monkeypatch):
+    """Whole-model gradients (encoders, converters, decoder, postnet) with every source of
+    randomness off (BN running statistics, no dropout, no noise): the HIP decoder backward inside
+    torch autograd vs the oracle's autograd.  (The interim torch BiLSTM needs train mode for its
+    backward, so the module is in train mode with BN / decoder in eval and dropout patched out.)"""
     att = SMA
     hp = hp_for(att)
     B, Tin, Tsub, T = 3, 13, 8, 12
-    m, hps = build_model(att)
+    m, hps = build_model(att, train=True)
+    import tacotron2_subword_amd.model as M
+    monkeypatch.setattr(M.F, "dropout", lambda x, p=0.5, training=True, inplace=False: x)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.eval()
+    m.decoder.eval()
     from tacotron2_subword_amd.loss_function import Tacotron2Loss
     batch = recipe.make_batch(hp, B, Tin, Tsub, T)
     x, y = m.parse_batch(batch)
