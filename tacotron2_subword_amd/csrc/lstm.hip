@@ -1,18 +1,21 @@
-// One LSTM time step for up to 4 independent cells in one launch ("streams": the phone and
-// sub-word attention LSTMs of Decoder.decode, or the two directions of an encoder BiLSTM).
+// LSTM time-step kernels (forward step; backward pointwise; backward recurrent-input GEMM) for up
+// to 4 independent cells per launch ("streams": the phone and sub-word attention LSTMs of
+// Decoder.decode, or the directions of an encoder BiLSTM).
 //
 //   gates = pre[b,:] (+bias1+bias2) + sum_seg x_seg[b,:] . W_seg[n,:]^T        (skinny GEMM, M = B)
 //   i,f,g,o = sigmoid, sigmoid, tanh, sigmoid ; c' = f*c + i*g ; h' = o*tanh(c')
 //   h_out = dropout(h'), c_out = dropout(c')                                   (model.py:340-346,371-373)
 //
-// Work split: one workgroup owns 8 hidden units = 32 gate rows of W for ALL batch rows, so every
-// weight element is read exactly once per step chip-wide (the step is weight-streaming bound).
-// Inside the workgroup the K range of every segment is split over the NW waves; each wave runs
-// v_mfma_f32_32x32x2_f32 on operands loaded straight from global memory (16 B per lane along K:
-// lane (r, hk) takes k = k0 + 4*hk + j for MFMA j — A and B use the same permutation, so the
-// sum is unchanged), then the NW partial tiles are summed through LDS in a fixed order.
-// Optionally the workgroup also emits its 8-unit partial of the attention query projection
-// W_q h (attention.py:368) so that no separate launch is needed between LSTM and attention.
+// Work split (forward): one workgroup owns 8 hidden units = 32 gate rows of W for ALL batch rows,
+// so every weight element is read exactly once per step chip-wide.  Operands are staged through LDS
+// in K-chunks of 64 with full-line global loads (16 B per lane, 256 B contiguous per row): loading
+// MFMA fragments straight from global memory touches 32 B of 32 different lines per instruction
+// and thrashes the 32 KB L1 (measured 4x slower).  LDS tiles are k-major with an ODD pitch, so both
+// the transposing stores (2-way, free) and the fragment reads (32 consecutive floats) are
+// conflict-free.  The 8 waves split each chunk's K (v_mfma_f32_32x32x2_f32, exact fp32 fma chains)
+// and their partial tiles are summed through LDS in a fixed order.  Optionally the workgroup also
+// emits its 8-unit partial of the attention query projection W_q h (attention.py:368) so that no
+// separate launch is needed between the LSTM and the attention kernel.
 #include "kernels.h"
 
 namespace t2 {
@@ -20,27 +23,69 @@ namespace t2 {
 namespace {
 
 constexpr int HU = 8;        // hidden units per workgroup
-constexpr int NW = 8;        // waves per workgroup (split-K)
+constexpr int NW = 8;        // waves per workgroup (split-K inside a chunk)
+constexpr int NTH = NW * 64;
 constexpr int PP = 33;       // LDS pitch of a 32-wide partial tile
+constexpr int BK = 64;       // K-chunk staged through LDS
+constexpr int PB = 33;       // pitch of the 32-wide B tile
+
+template <int MT> struct Tile {
+    static constexpr int PA = MT * 32 + 1;                     // odd pitch
+    static constexpr int A_FLOATS = BK * PA, B_FLOATS = BK * PB;
+    static constexpr int STAGE_FLOATS = 2 * (A_FLOATS + B_FLOATS);
+    static constexpr int SMEM_FLOATS = (STAGE_FLOATS > NW * 32 * PP ? STAGE_FLOATS : NW * 32 * PP);
+};
+
+// A tile: MT*32 rows x BK, source K-contiguous rows; thread q -> (row = q/16, 4 k's)
+template <int MT>
+__device__ __forceinline__ void load_a(const float* __restrict__ x, long ldx, int B, int k0, f32x4 (&ra)[MT]) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int q = threadIdx.x + i * NTH, row = q >> 4, k = k0 + (q & 15) * 4;
+        ra[i] = row < B ? *reinterpret_cast<const f32x4*>(x + (long)row * ldx + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+template <int MT>
+__device__ __forceinline__ void store_a(float* __restrict__ As, const f32x4 (&ra)[MT]) {
+    constexpr int PA = Tile<MT>::PA;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int q = threadIdx.x + i * NTH, row = q >> 4, k = (q & 15) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) As[(k + j) * PA + row] = ra[i][j];
+    }
+}
+// one chunk: wave w takes k-pairs [4w, 4w+4)
+template <int MT>
+__device__ __forceinline__ void compute_chunk(const float* __restrict__ As, const float* __restrict__ Bs, int wave, int r, int hk,
+                                              f32x16 (&acc)[MT]) {
+    constexpr int PA = Tile<MT>::PA;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2 / NW; ++kk) {
+        const int k = 2 * (wave * (BK / 2 / NW) + kk) + hk;
+        const float b = Bs[k * PB + r];
+        float a[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = As[k * PA + m * 32 + r];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b, acc[m], 0, 0, 0);
+    }
+}
 
 template <int MT>
-__global__ __launch_bounds__(NW * 64) void lstm_step_fwd_kernel(LstmStepDesc d) {
+__global__ __launch_bounds__(NTH) void lstm_step_fwd_kernel(LstmStepDesc d) {
+    using TL = Tile<MT>;
     const LstmStream& st = d.st[blockIdx.y];
     const int B = d.B, H = d.H;
     const int u0 = blockIdx.x * HU;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hk = lane >> 5;
-    const int wrow = (r >> 3) * H + u0 + (r & 7);    // column n = gate*8 + unit  ->  row of W
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* part = smem;                              // [NW][32][PP]
-    float* hs = smem + NW * 32 * PP;                 // [MT*32][HU]   post-dropout h of this group
-
-    f32x16 acc[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+    auto As = [&](int buf) { return smem + buf * TL::A_FLOATS; };
+    auto Bs = [&](int buf) { return smem + 2 * TL::A_FLOATS + buf * TL::B_FLOATS; };
+    float* part = smem;                              // [NW][32][PP], aliases the staging area after the K loop
+    float* hs = smem + TL::SMEM_FLOATS;              // [MT*32][HU]   post-dropout h of this group
 
     // The pointwise tail needs pre[b, g*H+u] (streamed once from HBM) and c_prev: request them
     // now so that their latency hides under the GEMM instead of being paid after it.
@@ -66,50 +111,40 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_fwd_kernel(LstmStepDesc d) 
         }
     }
 
-    for (int s = 0; s < st.nseg; ++s) {
-        const LstmSeg sg = st.seg[s];
-        const int kq = sg.k / NW;
-        const float* wp = sg.w + (long)wrow * sg.ldw + wave * kq + 4 * hk;
-        const float* xp[MT];
-        bool xv[MT];
+    f32x16 acc[MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int row = m * 32 + r;
-            xv[m] = row < B;
-            xp[m] = sg.x + (long)(xv[m] ? row : 0) * sg.ldx + wave * kq + 4 * hk;
-        }
-        // Keep many 16-byte loads in flight per wave: at one workgroup per CU the loop is bound by
-        // L2/MALL latency, not by the MFMA rate, unless ~100 KB per CU are outstanding.  So the
-        // operands of U k-steps are requested first and only then fed to the matrix core.
-        constexpr int U = MT <= 2 ? 8 : (MT <= 4 ? 4 : 1);
-        int k = 0;
-        for (; k + 8 * U <= kq; k += 8 * U) {
-            f32x4 w4[U], x4[U][MT];
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                w4[u] = *reinterpret_cast<const f32x4*>(wp + k + 8 * u);
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+
+    // B tile: 32 gate rows x BK; thread -> (n = tid/16, 4 k's); column n = gate*8 + unit -> row of W
+    const int bn = threadIdx.x >> 4, bk = (threadIdx.x & 15) * 4;
+    const int wrow = (bn >> 3) * H + u0 + (bn & 7);
+    int nchunks = 0;
+    for (int s = 0; s < st.nseg; ++s) nchunks += st.seg[s].k / BK;
+
+    f32x4 ra[MT], rb;
+    int seg = 0, kin = 0;                            // position of the NEXT chunk to load
+    auto load_next = [&]() {
+        const LstmSeg sg = st.seg[seg];
+        load_a<MT>(sg.x, sg.ldx, B, kin, ra);
+        rb = *reinterpret_cast<const f32x4*>(sg.w + (long)wrow * sg.ldw + kin + bk);
+        kin += BK;
+        if (kin >= sg.k) { kin = 0; ++seg; }
+    };
+    auto store_stage = [&](int buf) {
+        store_a<MT>(As(buf), ra);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) x4[u][m] = *reinterpret_cast<const f32x4*>(xp[m] + k + 8 * u);
-            }
-            __builtin_amdgcn_sched_barrier(0);      // all U*(1+MT) loads are issued before the first MFMA
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[m] ? x4[u][m][j] : 0.f, w4[u][j], acc[m], 0, 0, 0);
-        }
-        for (; k < kq; k += 8) {
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + k);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const f32x4 x4 = *reinterpret_cast<const f32x4*>(xp[m] + k);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[m] ? x4[j] : 0.f, w4[j], acc[m], 0, 0, 0);
-            }
-        }
+        for (int j = 0; j < 4; ++j) Bs(buf)[(bk + j) * PB + bn] = rb[j];
+    };
+    if (nchunks > 0) { load_next(); store_stage(0); }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int cur = c & 1;
+        if (c + 1 < nchunks) load_next();
+        compute_chunk<MT>(As(cur), Bs(cur), wave, r, hk, acc);
+        if (c + 1 < nchunks) store_stage(cur ^ 1);
+        __syncthreads();
     }
 
     const RngKey kh = rng_key(d.seed, st.site_h), kc = rng_key(d.seed, st.site_c);
@@ -169,12 +204,12 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_fwd_kernel(LstmStepDesc d) 
     if (st.wq) {
         // partial query projection of this unit group: qpart[group][b][a] = sum_uu h[b,u0+uu] * Wq[a,u0+uu]
         __syncthreads();
-        float* wqs = part;                            // [A][HU]   (A*HU <= NW*32*PP)
+        float* wqs = part;                            // [A][HU]
         const int A = st.A;
-        for (int i = threadIdx.x; i < A * HU; i += NW * 64) wqs[i] = st.wq[(long)(i / HU) * H + u0 + (i % HU)];
+        for (int i = threadIdx.x; i < A * HU; i += NTH) wqs[i] = st.wq[(long)(i / HU) * H + u0 + (i % HU)];
         __syncthreads();
         float* qp = st.qpart + (long)blockIdx.x * B * A;
-        for (int i = threadIdx.x; i < B * A; i += NW * 64) {
+        for (int i = threadIdx.x; i < B * A; i += NTH) {
             const int b = i / A, a = i % A;
             float sum = 0.f;
 #pragma unroll
@@ -183,7 +218,6 @@ __global__ __launch_bounds__(NW * 64) void lstm_step_fwd_kernel(LstmStepDesc d) 
         }
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // backward, part 1: pointwise.  One thread per (b, u).
@@ -239,11 +273,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(LstmBwdPointDes
 // ---------------------------------------------------------------------------------------------
 // backward, part 2: part[z][b][n] = sum_{k in K-split z} dg[b,k] * W[k,n]   for the recurrent
 // input columns n (ctx | h for the attention LSTMs, h for the decoder / encoder LSTMs).
-// grid = (column tiles of 32, K-splits, streams); inside a workgroup the K range is split again
-// over NW waves (v_mfma_f32_32x32x2_f32, operands from global memory) and summed through LDS.
+// grid = (column tiles of 32, K-splits, streams), so the whole chip works on one step; same
+// LDS-staged chunk pipeline as the forward step (A = dg rows, B = W rows k, n-contiguous).
 // ---------------------------------------------------------------------------------------------
 template <int MT>
-__global__ __launch_bounds__(NW * 64) void lstm_bwd_gemm_kernel(LstmBwdGemmDesc d) {
+__global__ __launch_bounds__(NTH) void lstm_bwd_gemm_kernel(LstmBwdGemmDesc d) {
+    using TL = Tile<MT>;
     const LstmBwdGemmStream& st = d.st[blockIdx.z];
     const int B = d.B;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -252,59 +287,47 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_gemm_kernel(LstmBwdGemmDesc 
     int col0 = blockIdx.x * 32, sidx = 0, cbase = 0;
     while (sidx < st.nseg - 1 && col0 >= cbase + st.seg[sidx].ncols) { cbase += st.seg[sidx].ncols; ++sidx; }
     const LstmBwdSeg sg = st.seg[sidx];
-    const int kspan = d.H4 / d.KS, kw = kspan / NW;
-    const int kbeg = blockIdx.y * kspan + wave * kw;
-    const float* wp = sg.w + (long)(kbeg + 4 * hk) * sg.ldw + (col0 - cbase) + r;
+    const int kspan = d.H4 / d.KS, kbeg = blockIdx.y * kspan;
+    const int nchunks = kspan / BK;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* part = smem;                              // [NW][32][PP]
+    auto As = [&](int buf) { return smem + buf * TL::A_FLOATS; };
+    auto Bs = [&](int buf) { return smem + 2 * TL::A_FLOATS + buf * TL::B_FLOATS; };
+    float* part = smem;
 
     f32x16 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
-    const float* xp[MT];
-    bool xv[MT];
+
+    // B tile: BK k-rows x 32 columns, n-contiguous; thread -> (k = tid/8, 4 n's)
+    const int bkr = threadIdx.x >> 3, bnq = (threadIdx.x & 7) * 4;
+    const float* wbase = sg.w + (long)(kbeg + bkr) * sg.ldw + (col0 - cbase) + bnq;
+    const bool wvec = (sg.ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(sg.w) & 15) == 0);
+    f32x4 ra[MT], rb;
+    auto load_chunk = [&](int c) {
+        load_a<MT>(st.dg, st.lddg, B, kbeg + c * BK, ra);
+        const float* p = wbase + (long)c * BK * sg.ldw;
+        if (wvec) rb = *reinterpret_cast<const f32x4*>(p);
+        else rb = f32x4{p[0], p[1], p[2], p[3]};
+    };
+    auto store_stage = [&](int buf) {
+        store_a<MT>(As(buf), ra);
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int row = m * 32 + r;
-        xv[m] = row < B;
-        xp[m] = st.dg + (long)(xv[m] ? row : 0) * st.lddg + kbeg + 4 * hk;
+        for (int j = 0; j < 4; ++j) Bs(buf)[bkr * PB + bnq + j] = rb[j];
+    };
+    load_chunk(0);
+    store_stage(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int cur = c & 1;
+        if (c + 1 < nchunks) load_chunk(c + 1);
+        compute_chunk<MT>(As(cur), Bs(cur), wave, r, hk, acc);
+        if (c + 1 < nchunks) store_stage(cur ^ 1);
+        __syncthreads();
     }
-    constexpr int U = MT <= 2 ? 4 : 2;
-    int k = 0;
-    for (; k + 8 * U <= kw; k += 8 * U) {
-        float w4[U][4];
-        f32x4 x4[U][MT];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) w4[u][j] = wp[(long)(k + 8 * u + j) * sg.ldw];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) x4[u][m] = *reinterpret_cast<const f32x4*>(xp[m] + k + 8 * u);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[m] ? x4[u][m][j] : 0.f, w4[u][j], acc[m], 0, 0, 0);
-    }
-    for (; k < kw; k += 8) {
-        float w4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w4[j] = wp[(long)(k + j) * sg.ldw];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const f32x4 x4 = *reinterpret_cast<const f32x4*>(xp[m] + k);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[m] ? x4[j] : 0.f, w4[j], acc[m], 0, 0, 0);
-        }
-    }
+
     float* out = st.part + (long)blockIdx.y * B * d.NC;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -313,7 +336,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_gemm_kernel(LstmBwdGemmDesc 
         for (int e = 0; e < 16; ++e)
             part[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk) * PP + r] = acc[m][e];
         __syncthreads();
-        for (int i = threadIdx.x; i < 32 * 32; i += NW * 64) {
+        for (int i = threadIdx.x; i < 32 * 32; i += NTH) {
             const int bl = i >> 5, c = i & 31, b = m * 32 + bl;
             if (b < B) {
                 float sum = 0.f;
@@ -324,6 +347,26 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_gemm_kernel(LstmBwdGemmDesc 
         }
     }
 }
+
+template <int MT> size_t fwd_smem() { return (size_t)(Tile<MT>::SMEM_FLOATS + MT * 32 * HU) * sizeof(float); }
+template <int MT> size_t bwd_smem() { return (size_t)Tile<MT>::SMEM_FLOATS * sizeof(float); }
+
+template <typename K>
+int allow_big_lds(K kernel, size_t smem) {
+    if (smem > 64 * 1024)
+        T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    return 0;
+}
+
+#define LAUNCH_MT(KERNEL, SMEM, GRID, BLOCK, STREAM, DESC)                                                      \
+    do {                                                                                                        \
+        int rc_ = 0;                                                                                            \
+        if (MT <= 1) { rc_ = allow_big_lds(KERNEL<1>, SMEM<1>()); if (!rc_) hipLaunchKernelGGL(KERNEL<1>, GRID, BLOCK, SMEM<1>(), STREAM, DESC); } \
+        else if (MT <= 2) { rc_ = allow_big_lds(KERNEL<2>, SMEM<2>()); if (!rc_) hipLaunchKernelGGL(KERNEL<2>, GRID, BLOCK, SMEM<2>(), STREAM, DESC); } \
+        else if (MT <= 4) { rc_ = allow_big_lds(KERNEL<4>, SMEM<4>()); if (!rc_) hipLaunchKernelGGL(KERNEL<4>, GRID, BLOCK, SMEM<4>(), STREAM, DESC); } \
+        else { rc_ = allow_big_lds(KERNEL<8>, SMEM<8>()); if (!rc_) hipLaunchKernelGGL(KERNEL<8>, GRID, BLOCK, SMEM<8>(), STREAM, DESC); } \
+        if (rc_) return rc_;                                                                                    \
+    } while (0)
 
 }  // namespace
 
@@ -336,26 +379,18 @@ int lstm_step_fwd(const LstmStepDesc& d, hipStream_t s) {
         T2_REQUIRE(st.nseg >= 0 && st.nseg <= kMaxSeg, "lstm_step: nseg=%d", st.nseg);
         for (int j = 0; j < st.nseg; ++j) {
             const LstmSeg& g = st.seg[j];
-            T2_REQUIRE(g.k % (8 * NW) == 0, "lstm_step: segment width %d must be a multiple of %d", g.k, 8 * NW);
+            T2_REQUIRE(g.k % BK == 0, "lstm_step: segment width %d must be a multiple of %d", g.k, BK);
             T2_REQUIRE(g.ldx % 4 == 0 && g.ldw % 4 == 0 && ((uintptr_t)g.x & 15) == 0 && ((uintptr_t)g.w & 15) == 0,
                        "lstm_step: segment %d operands must be 16-byte aligned (ldx=%ld ldw=%ld)", j, g.ldx, g.ldw);
         }
         T2_REQUIRE(!st.wq || st.A * HU <= NW * 32 * PP, "lstm_step: attention dim %d too large", st.A);
     }
     const int MT = (d.B + 31) / 32;
-    dim3 grid(d.H / HU, d.nstreams), block(NW * 64);
-    auto smem = [&](int mt) { return (size_t)(NW * 32 * PP + mt * 32 * HU) * sizeof(float); };
-    if (MT <= 1) hipLaunchKernelGGL(lstm_step_fwd_kernel<1>, grid, block, smem(1), s, d);
-    else if (MT <= 2) hipLaunchKernelGGL(lstm_step_fwd_kernel<2>, grid, block, smem(2), s, d);
-    else if (MT <= 4) hipLaunchKernelGGL(lstm_step_fwd_kernel<4>, grid, block, smem(4), s, d);
-    else hipLaunchKernelGGL(lstm_step_fwd_kernel<8>, grid, block, smem(8), s, d);
+    dim3 grid(d.H / HU, d.nstreams), block(NTH);
+    LAUNCH_MT(lstm_step_fwd_kernel, fwd_smem, grid, block, s, d);
     T2_LAUNCH_CHECK();
     return 0;
 }
-
-}  // namespace t2
-
-namespace t2 {
 
 int lstm_bwd_pointwise(const LstmBwdPointDesc& d, hipStream_t s) {
     T2_REQUIRE(d.nstreams >= 1 && d.nstreams <= kMaxLstmStreams, "lstm_bwd_pointwise: nstreams=%d", d.nstreams);
@@ -367,14 +402,14 @@ int lstm_bwd_pointwise(const LstmBwdPointDesc& d, hipStream_t s) {
 
 int lstm_bwd_ksplit(int H4) {
     int ks = 8;
-    while (ks > 1 && H4 % (ks * NW * 8) != 0) ks >>= 1;
+    while (ks > 1 && H4 % (ks * BK) != 0) ks >>= 1;
     return ks;
 }
 
 int lstm_bwd_gemm(const LstmBwdGemmDesc& d, hipStream_t s) {
     T2_REQUIRE(d.nstreams >= 1 && d.nstreams <= kMaxLstmStreams, "lstm_bwd_gemm: nstreams=%d", d.nstreams);
     T2_REQUIRE(d.B >= 1 && d.B <= 256, "lstm_bwd_gemm: batch %d", d.B);
-    T2_REQUIRE(d.KS >= 1 && d.H4 % (d.KS * NW * 8) == 0, "lstm_bwd_gemm: 4H=%d not divisible by KS*64 (KS=%d)", d.H4, d.KS);
+    T2_REQUIRE(d.KS >= 1 && d.H4 % (d.KS * BK) == 0, "lstm_bwd_gemm: 4H=%d not divisible by KS*%d (KS=%d)", d.H4, BK, d.KS);
     int nc = 0;
     for (int j = 0; j < d.st[0].nseg; ++j) nc += d.st[0].seg[j].ncols;
     T2_REQUIRE(nc == d.NC && nc % 32 == 0, "lstm_bwd_gemm: column count %d (NC=%d) must be a multiple of 32", nc, d.NC);
@@ -383,12 +418,8 @@ int lstm_bwd_gemm(const LstmBwdGemmDesc& d, hipStream_t s) {
         for (int j = 0; j < d.st[i].nseg; ++j) T2_REQUIRE(d.st[i].seg[j].ncols % 32 == 0, "lstm_bwd_gemm: segment cols %d", d.st[i].seg[j].ncols);
     }
     const int MT = (d.B + 31) / 32;
-    dim3 grid(d.NC / 32, d.KS, d.nstreams), block(NW * 64);
-    const size_t smem = (size_t)NW * 32 * PP * sizeof(float);
-    if (MT <= 1) hipLaunchKernelGGL(lstm_bwd_gemm_kernel<1>, grid, block, smem, s, d);
-    else if (MT <= 2) hipLaunchKernelGGL(lstm_bwd_gemm_kernel<2>, grid, block, smem, s, d);
-    else if (MT <= 4) hipLaunchKernelGGL(lstm_bwd_gemm_kernel<4>, grid, block, smem, s, d);
-    else hipLaunchKernelGGL(lstm_bwd_gemm_kernel<8>, grid, block, smem, s, d);
+    dim3 grid(d.NC / 32, d.KS, d.nstreams), block(NTH);
+    LAUNCH_MT(lstm_bwd_gemm_kernel, bwd_smem, grid, block, s, d);
     T2_LAUNCH_CHECK();
     return 0;
 }
