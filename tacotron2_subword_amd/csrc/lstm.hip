@@ -8,14 +8,16 @@
 //
 // Work split (forward): one workgroup owns 8 hidden units = 32 gate rows of W for ALL batch rows,
 // so every weight element is read exactly once per step chip-wide.  Operands are staged through LDS
-// in K-chunks of 64 with full-line global loads (16 B per lane, 256 B contiguous per row): loading
+// in wide K-stages with full-line global loads (16 B per lane, lanes along K): loading
 // MFMA fragments straight from global memory touches 32 B of 32 different lines per instruction
-// and thrashes the 32 KB L1 (measured 4x slower).  LDS tiles are k-major with an ODD pitch, so both
-// the transposing stores (2-way, free) and the fragment reads (32 consecutive floats) are
-// conflict-free.  The 8 waves split each chunk's K (v_mfma_f32_32x32x2_f32, exact fp32 fma chains)
+// and thrashes the 32 KB L1.  LDS tiles stay row-major at pitch K+4: ds_write_b128 stores and
+// ds_read_b128 fragment reads are both conflict-free.  The 8 waves split each stage's K (v_mfma_f32_32x32x2_f32, exact fp32 fma chains)
 // and their partial tiles are summed through LDS in a fixed order.  Optionally the workgroup also
 // emits its 8-unit partial of the attention query projection W_q h (attention.py:368) so that no
 // separate launch is needed between the LSTM and the attention kernel.
+#include <algorithm>
+#include <numeric>
+
 #include "kernels.h"
 
 namespace t2 {
@@ -23,58 +25,92 @@ namespace t2 {
 namespace {
 
 constexpr int HU = 8;        // hidden units per workgroup
-constexpr int NW = 8;        // waves per workgroup (split-K inside a chunk)
+constexpr int NW = 8;        // waves per workgroup (split-K inside a stage)
 constexpr int NTH = NW * 64;
 constexpr int PP = 33;       // LDS pitch of a 32-wide partial tile
-constexpr int BK = 64;       // K-chunk staged through LDS
-constexpr int PB = 33;       // pitch of the 32-wide B tile
 
-template <int MT> struct Tile {
-    static constexpr int PA = MT * 32 + 1;                     // odd pitch
-    static constexpr int A_FLOATS = BK * PA, B_FLOATS = BK * PB;
-    static constexpr int STAGE_FLOATS = 2 * (A_FLOATS + B_FLOATS);
-    static constexpr int SMEM_FLOATS = (STAGE_FLOATS > NW * 32 * PP ? STAGE_FLOATS : NW * 32 * PP);
+// One pipeline stage = BKT columns of K for all MT*32 batch rows (A) and the 32 output columns (B).
+// BKT is as large as LDS allows: with ONE workgroup per CU the only way to cover the ~1.5 us
+// L2-miss latency of the operand stream (activations were just written by another XCD, weights
+// come from MALL/HBM) is to have ~100 KB per CU in flight, i.e. to request the whole next stage
+// into registers before computing the current one.
+template <int MT, int BKT> struct Tile {
+    static constexpr int PA = BKT + 4;                         // row-major tiles, 16-byte aligned rows
+    static constexpr int A_FLOATS = MT * 32 * PA;
+    static constexpr int BF_FLOATS = 32 * PA;                  // forward B tile: [32 n][BKT]  (K-contiguous W rows)
+    static constexpr int PBN = 36;                             // backward B tile: [BKT k][32 n] (N-contiguous W rows)
+    static constexpr int BB_FLOATS = BKT * PBN;
+    static constexpr int QA = MT * 32 * (BKT / 4) / NTH;       // float4 per thread, A tile
+    static constexpr int QB = 32 * (BKT / 4) / NTH;            // float4 per thread, B tile (either layout)
+    static constexpr int FWD_FLOATS = (A_FLOATS + BF_FLOATS > NW * 32 * PP ? A_FLOATS + BF_FLOATS : NW * 32 * PP);
+    static constexpr int BWD_FLOATS = (A_FLOATS + BB_FLOATS > NW * 32 * PP ? A_FLOATS + BB_FLOATS : NW * 32 * PP);
 };
 
-// A tile: MT*32 rows x BK, source K-contiguous rows; thread q -> (row = q/16, 4 k's)
-template <int MT>
-__device__ __forceinline__ void load_a(const float* __restrict__ x, long ldx, int B, int k0, f32x4 (&ra)[MT]) {
+// Tile of R rows x BKT, K-contiguous source rows -> registers (16 B per lane, lanes along K: every
+// 128-byte line is requested once) -> LDS row-major with ds_write_b128.
+template <int R, int BKT, int Q, typename RowPtr>
+__device__ __forceinline__ void load_rows(RowPtr rowptr, int k0, f32x4 (&regs)[Q]) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int q = threadIdx.x + i * NTH, row = q >> 4, k = k0 + (q & 15) * 4;
-        ra[i] = row < B ? *reinterpret_cast<const f32x4*>(x + (long)row * ldx + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < Q; ++i) {
+        const int q = threadIdx.x + i * NTH, row = q / (BKT / 4), k = (q % (BKT / 4)) * 4;
+        const float* p = rowptr(row);
+        regs[i] = p ? *reinterpret_cast<const f32x4*>(p + k0 + k) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
-template <int MT>
-__device__ __forceinline__ void store_a(float* __restrict__ As, const f32x4 (&ra)[MT]) {
-    constexpr int PA = Tile<MT>::PA;
+template <int BKT, int Q>
+__device__ __forceinline__ void store_rows(float* __restrict__ lds, const f32x4 (&regs)[Q]) {
+    constexpr int P = BKT + 4;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int q = threadIdx.x + i * NTH, row = q >> 4, k = (q & 15) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) As[(k + j) * PA + row] = ra[i][j];
-    }
-}
-// one chunk: wave w takes k-pairs [4w, 4w+4)
-template <int MT>
-__device__ __forceinline__ void compute_chunk(const float* __restrict__ As, const float* __restrict__ Bs, int wave, int r, int hk,
-                                              f32x16 (&acc)[MT]) {
-    constexpr int PA = Tile<MT>::PA;
-#pragma unroll
-    for (int kk = 0; kk < BK / 2 / NW; ++kk) {
-        const int k = 2 * (wave * (BK / 2 / NW) + kk) + hk;
-        const float b = Bs[k * PB + r];
-        float a[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) a[m] = As[k * PA + m * 32 + r];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b, acc[m], 0, 0, 0);
+    for (int i = 0; i < Q; ++i) {
+        const int q = threadIdx.x + i * NTH, row = q / (BKT / 4), k = (q % (BKT / 4)) * 4;
+        *reinterpret_cast<f32x4*>(lds + row * P + k) = regs[i];
     }
 }
 
-template <int MT>
+// Forward stage: A [MT*32][PA], B [32][PA], both K-contiguous.  Wave w owns k in [w*BKT/8, (w+1)*BKT/8).
+// Lane (r, hk) reads 4 consecutive k (ds_read_b128, conflict-free at pitch BKT+4) and feeds element j
+// to MFMA j — A and B use the same k permutation, so each product pairs the same k.
+template <int MT, int BKT>
+__device__ __forceinline__ void compute_stage_fwd(const float* __restrict__ As, const float* __restrict__ Bs, int wave, int r, int hk,
+                                                  f32x16 (&acc)[MT]) {
+    constexpr int PA = BKT + 4;
+#pragma unroll
+    for (int kk = 0; kk < BKT / NW; kk += 8) {
+        const int k = wave * (BKT / NW) + kk + 4 * hk;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(Bs + r * PA + k);
+        f32x4 a4[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a4[m] = *reinterpret_cast<const f32x4*>(As + (m * 32 + r) * PA + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m][j], b4[j], acc[m], 0, 0, 0);
+    }
+}
+// Backward stage: A as above, B [BKT k][PBN] with n contiguous.
+template <int MT, int BKT>
+__device__ __forceinline__ void compute_stage_bwd(const float* __restrict__ As, const float* __restrict__ Bs, int wave, int r, int hk,
+                                                  f32x16 (&acc)[MT]) {
+    constexpr int PA = BKT + 4, PBN = Tile<MT, BKT>::PBN;
+#pragma unroll
+    for (int kk = 0; kk < BKT / NW; kk += 8) {
+        const int k = wave * (BKT / NW) + kk + 4 * hk;
+        float b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = Bs[(k + j) * PBN + r];
+        f32x4 a4[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a4[m] = *reinterpret_cast<const f32x4*>(As + (m * 32 + r) * PA + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m][j], b[j], acc[m], 0, 0, 0);
+    }
+}
+
+template <int MT, int BKT>
 __global__ __launch_bounds__(NTH) void lstm_step_fwd_kernel(LstmStepDesc d) {
-    using TL = Tile<MT>;
+    using TL = Tile<MT, BKT>;
     const LstmStream& st = d.st[blockIdx.y];
     const int B = d.B, H = d.H;
     const int u0 = blockIdx.x * HU;
@@ -82,10 +118,10 @@ __global__ __launch_bounds__(NTH) void lstm_step_fwd_kernel(LstmStepDesc d) {
     const int r = lane & 31, hk = lane >> 5;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    auto As = [&](int buf) { return smem + buf * TL::A_FLOATS; };
-    auto Bs = [&](int buf) { return smem + 2 * TL::A_FLOATS + buf * TL::B_FLOATS; };
+    float* As = smem;
+    float* Bs = smem + TL::A_FLOATS;
     float* part = smem;                              // [NW][32][PP], aliases the staging area after the K loop
-    float* hs = smem + TL::SMEM_FLOATS;              // [MT*32][HU]   post-dropout h of this group
+    float* hs = smem + TL::FWD_FLOATS;               // [MT*32][HU]   post-dropout h of this group
 
     // The pointwise tail needs pre[b, g*H+u] (streamed once from HBM) and c_prev: request them
     // now so that their latency hides under the GEMM instead of being paid after it.
@@ -117,34 +153,35 @@ __global__ __launch_bounds__(NTH) void lstm_step_fwd_kernel(LstmStepDesc d) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
 
-    // B tile: 32 gate rows x BK; thread -> (n = tid/16, 4 k's); column n = gate*8 + unit -> row of W
-    const int bn = threadIdx.x >> 4, bk = (threadIdx.x & 15) * 4;
-    const int wrow = (bn >> 3) * H + u0 + (bn & 7);
-    int nchunks = 0;
-    for (int s = 0; s < st.nseg; ++s) nchunks += st.seg[s].k / BK;
+    int nstages = 0;
+    for (int s = 0; s < st.nseg; ++s) nstages += st.seg[s].k / BKT;
 
-    f32x4 ra[MT], rb;
-    int seg = 0, kin = 0;                            // position of the NEXT chunk to load
+    f32x4 ra[TL::QA], rb[TL::QB];
+    int seg = 0, kin = 0;                            // position of the NEXT stage to load
     auto load_next = [&]() {
         const LstmSeg sg = st.seg[seg];
-        load_a<MT>(sg.x, sg.ldx, B, kin, ra);
-        rb = *reinterpret_cast<const f32x4*>(sg.w + (long)wrow * sg.ldw + kin + bk);
-        kin += BK;
+        load_rows<MT * 32, BKT, TL::QA>([&](int row) { return row < B ? sg.x + (long)row * sg.ldx : nullptr; }, kin, ra);
+        // column n = gate*8 + unit  ->  row (n/8)*H + u0 + n%8 of W
+        load_rows<32, BKT, TL::QB>([&](int n) { return sg.w + (long)((n >> 3) * H + u0 + (n & 7)) * sg.ldw; }, kin, rb);
+        kin += BKT;
         if (kin >= sg.k) { kin = 0; ++seg; }
     };
-    auto store_stage = [&](int buf) {
-        store_a<MT>(As(buf), ra);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Bs(buf)[(bk + j) * PB + bn] = rb[j];
-    };
-    if (nchunks > 0) { load_next(); store_stage(0); }
+    if (nstages > 0) {
+        load_next();
+        store_rows<BKT, TL::QA>(As, ra);
+        store_rows<BKT, TL::QB>(Bs, rb);
+    }
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int cur = c & 1;
-        if (c + 1 < nchunks) load_next();
-        compute_chunk<MT>(As(cur), Bs(cur), wave, r, hk, acc);
-        if (c + 1 < nchunks) store_stage(cur ^ 1);
+    for (int c = 0; c < nstages; ++c) {
+        const bool more = c + 1 < nstages;
+        if (more) load_next();                       // the whole next stage is in flight during the MFMAs
+        compute_stage_fwd<MT, BKT>(As, Bs, wave, r, hk, acc);
         __syncthreads();
+        if (more) {
+            store_rows<BKT, TL::QA>(As, ra);
+            store_rows<BKT, TL::QB>(Bs, rb);
+            __syncthreads();
+        }
     }
 
     const RngKey kh = rng_key(d.seed, st.site_h), kc = rng_key(d.seed, st.site_c);
@@ -276,9 +313,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(LstmBwdPointDes
 // grid = (column tiles of 32, K-splits, streams), so the whole chip works on one step; same
 // LDS-staged chunk pipeline as the forward step (A = dg rows, B = W rows k, n-contiguous).
 // ---------------------------------------------------------------------------------------------
-template <int MT>
+template <int MT, int BKT>
 __global__ __launch_bounds__(NTH) void lstm_bwd_gemm_kernel(LstmBwdGemmDesc d) {
-    using TL = Tile<MT>;
+    using TL = Tile<MT, BKT>;
     const LstmBwdGemmStream& st = d.st[blockIdx.z];
     const int B = d.B;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -288,11 +325,11 @@ __global__ __launch_bounds__(NTH) void lstm_bwd_gemm_kernel(LstmBwdGemmDesc d) {
     while (sidx < st.nseg - 1 && col0 >= cbase + st.seg[sidx].ncols) { cbase += st.seg[sidx].ncols; ++sidx; }
     const LstmBwdSeg sg = st.seg[sidx];
     const int kspan = d.H4 / d.KS, kbeg = blockIdx.y * kspan;
-    const int nchunks = kspan / BK;
+    const int nstages = kspan / BKT;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    auto As = [&](int buf) { return smem + buf * TL::A_FLOATS; };
-    auto Bs = [&](int buf) { return smem + 2 * TL::A_FLOATS + buf * TL::B_FLOATS; };
+    float* As = smem;
+    float* Bs = smem + TL::A_FLOATS;
     float* part = smem;
 
     f32x16 acc[MT];
@@ -301,31 +338,37 @@ __global__ __launch_bounds__(NTH) void lstm_bwd_gemm_kernel(LstmBwdGemmDesc d) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
 
-    // B tile: BK k-rows x 32 columns, n-contiguous; thread -> (k = tid/8, 4 n's)
-    const int bkr = threadIdx.x >> 3, bnq = (threadIdx.x & 7) * 4;
-    const float* wbase = sg.w + (long)(kbeg + bkr) * sg.ldw + (col0 - cbase) + bnq;
+    // B tile: BKT k-rows x 32 columns, n-contiguous: thread quad q -> (k = q/8, 4 n's)
+    const float* wbase = sg.w + (long)kbeg * sg.ldw + (col0 - cbase);
     const bool wvec = (sg.ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(sg.w) & 15) == 0);
-    f32x4 ra[MT], rb;
-    auto load_chunk = [&](int c) {
-        load_a<MT>(st.dg, st.lddg, B, kbeg + c * BK, ra);
-        const float* p = wbase + (long)c * BK * sg.ldw;
-        if (wvec) rb = *reinterpret_cast<const f32x4*>(p);
-        else rb = f32x4{p[0], p[1], p[2], p[3]};
-    };
-    auto store_stage = [&](int buf) {
-        store_a<MT>(As(buf), ra);
+    f32x4 ra[TL::QA], rb[TL::QB];
+    auto load_stage = [&](int c) {
+        load_rows<MT * 32, BKT, TL::QA>([&](int row) { return row < B ? st.dg + (long)row * st.lddg + kbeg : nullptr; }, c * BKT, ra);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Bs(buf)[bkr * PB + bnq + j] = rb[j];
+        for (int i = 0; i < TL::QB; ++i) {
+            const int q = threadIdx.x + i * NTH, k = q >> 3, n = (q & 7) * 4;
+            const float* p = wbase + (long)(c * BKT + k) * sg.ldw + n;
+            if (wvec) rb[i] = *reinterpret_cast<const f32x4*>(p);
+            else rb[i] = f32x4{p[0], p[1], p[2], p[3]};
+        }
     };
-    load_chunk(0);
-    store_stage(0);
+    auto store_stage = [&]() {
+        store_rows<BKT, TL::QA>(As, ra);
+#pragma unroll
+        for (int i = 0; i < TL::QB; ++i) {
+            const int q = threadIdx.x + i * NTH, k = q >> 3, n = (q & 7) * 4;
+            *reinterpret_cast<f32x4*>(Bs + k * TL::PBN + n) = rb[i];
+        }
+    };
+    load_stage(0);
+    store_stage();
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int cur = c & 1;
-        if (c + 1 < nchunks) load_chunk(c + 1);
-        compute_chunk<MT>(As(cur), Bs(cur), wave, r, hk, acc);
-        if (c + 1 < nchunks) store_stage(cur ^ 1);
+    for (int c = 0; c < nstages; ++c) {
+        const bool more = c + 1 < nstages;
+        if (more) load_stage(c + 1);
+        compute_stage_bwd<MT, BKT>(As, Bs, wave, r, hk, acc);
         __syncthreads();
+        if (more) { store_stage(); __syncthreads(); }
     }
 
     float* out = st.part + (long)blockIdx.y * B * d.NC;
@@ -348,8 +391,8 @@ __global__ __launch_bounds__(NTH) void lstm_bwd_gemm_kernel(LstmBwdGemmDesc d) {
     }
 }
 
-template <int MT> size_t fwd_smem() { return (size_t)(Tile<MT>::SMEM_FLOATS + MT * 32 * HU) * sizeof(float); }
-template <int MT> size_t bwd_smem() { return (size_t)Tile<MT>::SMEM_FLOATS * sizeof(float); }
+template <int MT, int BKT> size_t fwd_smem() { return (size_t)(Tile<MT, BKT>::FWD_FLOATS + MT * 32 * HU) * sizeof(float); }
+template <int MT, int BKT> size_t bwd_smem() { return (size_t)Tile<MT, BKT>::BWD_FLOATS * sizeof(float); }
 
 template <typename K>
 int allow_big_lds(K kernel, size_t smem) {
@@ -358,14 +401,20 @@ int allow_big_lds(K kernel, size_t smem) {
     return 0;
 }
 
-#define LAUNCH_MT(KERNEL, SMEM, GRID, BLOCK, STREAM, DESC)                                                      \
-    do {                                                                                                        \
-        int rc_ = 0;                                                                                            \
-        if (MT <= 1) { rc_ = allow_big_lds(KERNEL<1>, SMEM<1>()); if (!rc_) hipLaunchKernelGGL(KERNEL<1>, GRID, BLOCK, SMEM<1>(), STREAM, DESC); } \
-        else if (MT <= 2) { rc_ = allow_big_lds(KERNEL<2>, SMEM<2>()); if (!rc_) hipLaunchKernelGGL(KERNEL<2>, GRID, BLOCK, SMEM<2>(), STREAM, DESC); } \
-        else if (MT <= 4) { rc_ = allow_big_lds(KERNEL<4>, SMEM<4>()); if (!rc_) hipLaunchKernelGGL(KERNEL<4>, GRID, BLOCK, SMEM<4>(), STREAM, DESC); } \
-        else { rc_ = allow_big_lds(KERNEL<8>, SMEM<8>()); if (!rc_) hipLaunchKernelGGL(KERNEL<8>, GRID, BLOCK, SMEM<8>(), STREAM, DESC); } \
-        if (rc_) return rc_;                                                                                    \
+// stage width by batch tile count (LDS budget) when every K extent allows it, else 64
+#define LAUNCH_ONE(KERNEL, SMEM, MTV, BKV, GRID, BLOCK, STREAM, DESC)                                 \
+    do {                                                                                              \
+        const size_t sm_ = SMEM<MTV, BKV>();                                                          \
+        int rc_ = allow_big_lds(KERNEL<MTV, BKV>, sm_);                                               \
+        if (rc_) return rc_;                                                                          \
+        hipLaunchKernelGGL((KERNEL<MTV, BKV>), GRID, BLOCK, sm_, STREAM, DESC);                       \
+    } while (0)
+#define LAUNCH_MT(KERNEL, SMEM, KDIV, GRID, BLOCK, STREAM, DESC)                                      \
+    do {                                                                                              \
+        if (MT <= 1) { if ((KDIV) % 256 == 0) LAUNCH_ONE(KERNEL, SMEM, 1, 256, GRID, BLOCK, STREAM, DESC); else LAUNCH_ONE(KERNEL, SMEM, 1, 64, GRID, BLOCK, STREAM, DESC); } \
+        else if (MT <= 2) { if ((KDIV) % 256 == 0) LAUNCH_ONE(KERNEL, SMEM, 2, 256, GRID, BLOCK, STREAM, DESC); else LAUNCH_ONE(KERNEL, SMEM, 2, 64, GRID, BLOCK, STREAM, DESC); } \
+        else if (MT <= 4) { if ((KDIV) % 128 == 0) LAUNCH_ONE(KERNEL, SMEM, 4, 128, GRID, BLOCK, STREAM, DESC); else LAUNCH_ONE(KERNEL, SMEM, 4, 64, GRID, BLOCK, STREAM, DESC); } \
+        else LAUNCH_ONE(KERNEL, SMEM, 8, 64, GRID, BLOCK, STREAM, DESC);                              \
     } while (0)
 
 }  // namespace
@@ -379,7 +428,7 @@ int lstm_step_fwd(const LstmStepDesc& d, hipStream_t s) {
         T2_REQUIRE(st.nseg >= 0 && st.nseg <= kMaxSeg, "lstm_step: nseg=%d", st.nseg);
         for (int j = 0; j < st.nseg; ++j) {
             const LstmSeg& g = st.seg[j];
-            T2_REQUIRE(g.k % BK == 0, "lstm_step: segment width %d must be a multiple of %d", g.k, BK);
+            T2_REQUIRE(g.k % 64 == 0, "lstm_step: segment width %d must be a multiple of 64", g.k);
             T2_REQUIRE(g.ldx % 4 == 0 && g.ldw % 4 == 0 && ((uintptr_t)g.x & 15) == 0 && ((uintptr_t)g.w & 15) == 0,
                        "lstm_step: segment %d operands must be 16-byte aligned (ldx=%ld ldw=%ld)", j, g.ldx, g.ldw);
         }
@@ -387,7 +436,11 @@ int lstm_step_fwd(const LstmStepDesc& d, hipStream_t s) {
     }
     const int MT = (d.B + 31) / 32;
     dim3 grid(d.H / HU, d.nstreams), block(NTH);
-    LAUNCH_MT(lstm_step_fwd_kernel, fwd_smem, grid, block, s, d);
+    int kdiv = 0;                                    // gcd-like: every segment width must be a multiple of the stage width
+    for (int i = 0; i < d.nstreams; ++i)
+        for (int j = 0; j < d.st[i].nseg; ++j) kdiv = kdiv == 0 ? d.st[i].seg[j].k : std::gcd(kdiv, d.st[i].seg[j].k);
+    if (kdiv == 0) kdiv = 256;
+    LAUNCH_MT(lstm_step_fwd_kernel, fwd_smem, kdiv, grid, block, s, d);
     T2_LAUNCH_CHECK();
     return 0;
 }
@@ -402,14 +455,14 @@ int lstm_bwd_pointwise(const LstmBwdPointDesc& d, hipStream_t s) {
 
 int lstm_bwd_ksplit(int H4) {
     int ks = 8;
-    while (ks > 1 && H4 % (ks * BK) != 0) ks >>= 1;
+    while (ks > 1 && H4 % (ks * 64) != 0) ks >>= 1;
     return ks;
 }
 
 int lstm_bwd_gemm(const LstmBwdGemmDesc& d, hipStream_t s) {
     T2_REQUIRE(d.nstreams >= 1 && d.nstreams <= kMaxLstmStreams, "lstm_bwd_gemm: nstreams=%d", d.nstreams);
     T2_REQUIRE(d.B >= 1 && d.B <= 256, "lstm_bwd_gemm: batch %d", d.B);
-    T2_REQUIRE(d.KS >= 1 && d.H4 % (d.KS * BK) == 0, "lstm_bwd_gemm: 4H=%d not divisible by KS*%d (KS=%d)", d.H4, BK, d.KS);
+    T2_REQUIRE(d.KS >= 1 && d.H4 % (d.KS * 64) == 0, "lstm_bwd_gemm: 4H=%d not divisible by KS*64 (KS=%d)", d.H4, d.KS);
     int nc = 0;
     for (int j = 0; j < d.st[0].nseg; ++j) nc += d.st[0].seg[j].ncols;
     T2_REQUIRE(nc == d.NC && nc % 32 == 0, "lstm_bwd_gemm: column count %d (NC=%d) must be a multiple of 32", nc, d.NC);
@@ -419,7 +472,7 @@ int lstm_bwd_gemm(const LstmBwdGemmDesc& d, hipStream_t s) {
     }
     const int MT = (d.B + 31) / 32;
     dim3 grid(d.NC / 32, d.KS, d.nstreams), block(NTH);
-    LAUNCH_MT(lstm_bwd_gemm_kernel, bwd_smem, grid, block, s, d);
+    LAUNCH_MT(lstm_bwd_gemm_kernel, bwd_smem, d.H4 / d.KS, grid, block, s, d);
     T2_LAUNCH_CHECK();
     return 0;
 }
