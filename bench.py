@@ -160,13 +160,20 @@ def main():
                 e["gbs"] = round(by[k] / (avg_us * 1e-6) / 1e9, 1)
             kernels[k] = e
         dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
+        traffic = None                      # HBM-side bytes per launch from the committed rocprofv3 PMC passes
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        tkey = {"att_lstm_fwd": "lstm_step_fwd_grid131072", "dec_lstm_fwd": "lstm_step_fwd_grid65536",
+                "attention_fwd": "attention_step_fwd_grid131072", "attention_bwd": "attention_step_bwd_grid65536",
+                "att_lstm_bwd_gemm": "lstm_bwd_gemm_grid393216", "dec_lstm_bwd_gemm": "lstm_bwd_gemm_grid131072"}.get(dom)
+        if os.path.exists(tpath) and tkey and (B, Tin, Tsub) == (64, 100, 60):
+            traffic = json.load(open(tpath)).get(tkey, {}).get("hbm_bytes_per_launch")
         if dom in fl:
             roof = dict(kernel=dom, bound="mfma", achieved=kernels[dom]["tflops"], peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(kernels[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                        frac=round(kernels[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
                         note="fp32 MFMA (v_mfma_f32_32x32x2_f32) peak; algorithmic FLOPs per launch / avg HIP-event duration")
         else:
             roof = dict(kernel=dom, bound="hbm", achieved=kernels[dom]["gbs"], peak=PEAK_HBM_GBS, unit="GB/s",
-                        frac=round(kernels[dom]["gbs"] / PEAK_HBM_GBS, 4), traffic=None)
+                        frac=round(kernels[dom]["gbs"] / PEAK_HBM_GBS, 4), traffic=traffic)
 
     if world > 1:
         torch.distributed.barrier()

@@ -1,0 +1,22 @@
+"""Dev tool (diagnostic build with -DT2_STAMPS only): where one LSTM step launch spends its time."""
+import ctypes as C, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from oracle import recipe
+from helpers import hp_for, to_dev, SMA
+from tacotron2_subword_amd import _lib as L, ops
+hp = hp_for(SMA); P = to_dev(recipe.make_weights(hp)); dims = L.dims_from_hparams(hp)
+W = L.decoder_weights(P, dims.attention_kind)
+B, T = 64, 24
+mem = torch.randn(B, 100, 512, device="cuda") * .5; mems = torch.randn(B, 60, 512, device="cuda") * .5
+mels = torch.randn(B, 80, T, device="cuda"); tl = torch.full((B,), 100, device="cuda"); bl = torch.full((B,), 60, device="cuda")
+for _ in range(3):
+    dp = ops.decoder_forward(W, dims, mem, mems, tl, bl, mels, training=True, prenet_dropout=True, seed=1)
+torch.cuda.synchronize()
+buf = (C.c_ulonglong * 16)()
+L.lib().t2_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
+print("rc", L.lib().t2_debug_read_stamps(buf, 16))
+for name, o in (("att (2 streams)", 0), ("dec", 8)):
+    v = [buf[o + i] for i in range(5)]
+    print(name, "entry->staged %.2f us | K loop %.2f us | epilogue %.2f us | query partials %.2f us | total %.2f us" % tuple(
+        [(v[i + 1] - v[i]) / 100.0 for i in range(4)] + [(v[4] - v[0]) / 100.0]))

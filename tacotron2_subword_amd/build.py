@@ -32,7 +32,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(o)
         if not force and os.path.exists(o) and os.path.getmtime(o) >= _newest(deps):
             continue
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-c", s, "-o", o]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed"] + os.environ.get("T2_EXTRA_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -20,6 +20,21 @@
 
 #include "kernels.h"
 
+#ifdef T2_STAMPS
+__device__ unsigned long long t2_stamps[32];
+#define T2_STAMP(i)                                                                              \
+    do {                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x == 0 && d.st[0].t == 0 && d.st[0].nseg > 0) t2_stamps[(d.nstreams == 2 ? 0 : 8) + i] = __builtin_amdgcn_s_memrealtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    } while (0)
+extern "C" int t2_debug_read_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(t2_stamps), sizeof(unsigned long long) * n);
+}
+#else
+#define T2_STAMP(i)
+#endif
+
 namespace t2 {
 
 namespace {
@@ -117,14 +132,36 @@ __global__ __launch_bounds__(NTH) void lstm_step_fwd_kernel(LstmStepDesc d) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hk = lane >> 5;
 
+    T2_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + TL::A_FLOATS;
     float* part = smem;                              // [NW][32][PP], aliases the staging area after the K loop
     float* hs = smem + TL::FWD_FLOATS;               // [MT*32][HU]   post-dropout h of this group
 
-    // The pointwise tail needs pre[b, g*H+u] (streamed once from HBM) and c_prev: request them
-    // now so that their latency hides under the GEMM instead of being paid after it.
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+
+    int nstages = 0;
+    for (int s = 0; s < st.nseg; ++s) nstages += st.seg[s].k / BKT;
+
+    f32x4 ra[TL::QA], rb[TL::QB];
+    int seg = 0, kin = 0;                            // position of the NEXT stage to load
+    auto load_next = [&]() {
+        const LstmSeg sg = st.seg[seg];
+        load_rows<MT * 32, BKT, TL::QA>([&](int row) { return row < B ? sg.x + (long)row * sg.ldx : nullptr; }, kin, ra);
+        // column n = gate*8 + unit  ->  row (n/8)*H + u0 + n%8 of W
+        load_rows<32, BKT, TL::QB>([&](int n) { return sg.w + (long)((n >> 3) * H + u0 + (n & 7)) * sg.ldw; }, kin, rb);
+        kin += BKT;
+        if (kin >= sg.k) { kin = 0; ++seg; }
+    };
+    if (nstages > 0) load_next();
+    // The pointwise tail needs pre[b, g*H+u] (streamed once from HBM) and c_prev: request them now so
+    // that their latency hides under the GEMM — but AFTER the first stage's operands (vector-memory
+    // operations complete in order: stage 0 must not queue behind these cold reads).
     constexpr bool kPrefetch = MT <= 4;
     float pre_v[kPrefetch ? MT : 1][4];
     float cp_v[kPrefetch ? MT : 1];
@@ -147,31 +184,12 @@ __global__ __launch_bounds__(NTH) void lstm_step_fwd_kernel(LstmStepDesc d) {
         }
     }
 
-    f32x16 acc[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
-
-    int nstages = 0;
-    for (int s = 0; s < st.nseg; ++s) nstages += st.seg[s].k / BKT;
-
-    f32x4 ra[TL::QA], rb[TL::QB];
-    int seg = 0, kin = 0;                            // position of the NEXT stage to load
-    auto load_next = [&]() {
-        const LstmSeg sg = st.seg[seg];
-        load_rows<MT * 32, BKT, TL::QA>([&](int row) { return row < B ? sg.x + (long)row * sg.ldx : nullptr; }, kin, ra);
-        // column n = gate*8 + unit  ->  row (n/8)*H + u0 + n%8 of W
-        load_rows<32, BKT, TL::QB>([&](int n) { return sg.w + (long)((n >> 3) * H + u0 + (n & 7)) * sg.ldw; }, kin, rb);
-        kin += BKT;
-        if (kin >= sg.k) { kin = 0; ++seg; }
-    };
     if (nstages > 0) {
-        load_next();
         store_rows<BKT, TL::QA>(As, ra);
         store_rows<BKT, TL::QB>(Bs, rb);
     }
     __syncthreads();
+    T2_STAMP(1);
     for (int c = 0; c < nstages; ++c) {
         const bool more = c + 1 < nstages;
         if (more) load_next();                       // the whole next stage is in flight during the MFMAs
@@ -184,6 +202,7 @@ __global__ __launch_bounds__(NTH) void lstm_step_fwd_kernel(LstmStepDesc d) {
         }
     }
 
+    T2_STAMP(2);
     const RngKey kh = rng_key(d.seed, st.site_h), kc = rng_key(d.seed, st.site_c);
     const float scale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
 #pragma unroll
@@ -238,6 +257,7 @@ __global__ __launch_bounds__(NTH) void lstm_step_fwd_kernel(LstmStepDesc d) {
         }
     }
 
+    T2_STAMP(3);
     if (st.wq) {
         // partial query projection of this unit group: qpart[group][b][a] = sum_uu h[b,u0+uu] * Wq[a,u0+uu]
         __syncthreads();
@@ -254,6 +274,7 @@ __global__ __launch_bounds__(NTH) void lstm_step_fwd_kernel(LstmStepDesc d) {
             qp[i] = sum;
         }
     }
+    T2_STAMP(4);
 }
 
 // ---------------------------------------------------------------------------------------------
