@@ -178,6 +178,82 @@ int t2_decoder_infer(const t2_dims* dims, const t2_decoder_weights* w, const t2_
 int t2_finalize_bct(const float* in_btc, float* out_bct, int B, int T, int C, const int32_t* lengths, float fill, void* stream);
 int t2_mask_bt(float* x, int B, int T, const int32_t* lengths, float fill, void* stream);
 
+/* ---- Encoder / Postnet building blocks (channels-last frames x[B*T, C]) --------------------------
+ * One Conv1d(k, same padding) + BatchNorm1d + activation + dropout layer, forward and backward:
+ * replaces one nn.Sequential(ConvNorm, BatchNorm1d) + torch.tanh/F.relu + F.dropout of
+ * Postnet.forward (model.py:65-70) / Encoder.forward (model.py:97-99).  act: 0 none, 1 relu, 2 tanh.
+ * Dropout keep-bit index = (b*T + t)*Cout + c at `site`.  Saved tensors (z, mean, invstd) are
+ * caller-owned and passed back to the backward call. */
+typedef struct t2_conv_bn_args {
+    int B, T, Cin, Cout, K;
+    const float* x;                    /* [B*T, Cin] */
+    const float* w; const float* bias; /* conv.weight [Cout,Cin,K], conv.bias [Cout] */
+    const float* gamma; const float* beta;   /* BatchNorm weight / bias */
+    float* run_mean; float* run_var;   /* running statistics: updated in training, read in eval */
+    int training; float eps; int act; float drop_p; uint64_t seed; uint32_t site;
+    const float* residual;             /* optional, added to the output (mel + postnet(mel), model.py:558) */
+    float* z; float* mean; float* invstd; float* var;   /* saved: [B*T,Cout], [Cout] x3 */
+    float* y;                          /* [B*T, Cout] */
+    float* ws; size_t ws_floats;       /* scratch >= Cout*Cin*K + 128*Cout floats */
+} t2_conv_bn_args;
+int t2_conv_bn_forward(const t2_conv_bn_args* a, void* stream);
+typedef struct t2_conv_bn_bwd_args {
+    int B, T, Cin, Cout, K;
+    const float* x; const float* w; const float* gamma; const float* beta;
+    const float* z; const float* mean; const float* invstd;
+    int training; float eps; int act; float drop_p; uint64_t seed; uint32_t site;
+    const float* dy;                   /* [B*T, Cout] */
+    float* dw; float* dbias; float* dgamma; float* dbeta;
+    float* dx; int dx_accumulate;      /* [B*T, Cin] or NULL */
+    float* ws; size_t ws_floats;       /* scratch >= B*T*Cout + Cout*Cin*K + 128*Cout + split-K space */
+} t2_conv_bn_bwd_args;
+int t2_conv_bn_backward(const t2_conv_bn_bwd_args* a, void* stream);
+
+/* nn.Embedding forward / weight gradient (model.py:501-502,546,551); ids are int64. */
+int t2_embedding_forward(const int64_t* ids, const float* table, float* out, int rows, int dim, void* stream);
+int t2_embedding_backward(const int64_t* ids, const float* dout, float* dtable, int rows, int dim, int vocab, void* stream);
+
+/* LSTM recurrences over whole sequences with precomputed input pre-activations (time-major
+ * [T,B,4H], biases included): the packed BiLSTM of Encoder.forward (model.py:104-112; lengths given)
+ * or the unpacked one of Encoder.inference (:122-123; lengths NULL).  Up to 4 independent
+ * sequences ("streams": directions / encoders) advance together, one kernel launch per time step.
+ * Outputs beyond an item's length are zero and its state stays zero, which is exactly
+ * pack_padded_sequence / pad_packed_sequence semantics for both directions. */
+typedef struct t2_lstm_seq_args {
+    int nstreams, B, T, H;
+    const float* pre[4];     /* [T,B,4H] */
+    const float* w_hh[4];    /* [4H,H] */
+    int reverse[4];
+    const int32_t* lengths;  /* [B] or NULL */
+    float* h[4]; long ldh;   /* [T,B,*]: row stride ldh (lets two directions share one [T,B,2H] buffer) */
+    float* c[4];             /* [T,B,H] saved cells */
+    float* gates[4];         /* [T,B,4H] saved activated gates */
+} t2_lstm_seq_args;
+int t2_lstm_seq_forward(const t2_lstm_seq_args* a, void* stream);
+typedef struct t2_lstm_seq_bwd_args {
+    int nstreams, B, T, H;
+    const float* w_hh[4]; int reverse[4];
+    const float* h[4]; long ldh; const float* c[4]; const float* gates[4];
+    const float* dh[4]; long lddh;   /* gradient on the outputs, [T,B,*] with row stride lddh */
+    float* dpre[4];                  /* out: gradient wrt pre-activations [T,B,4H] */
+    float* dw_hh[4];                 /* out: [4H,H] */
+    float* ws; size_t ws_floats;     /* scratch >= nstreams*(B*H + 8*B*H) + split-K space */
+} t2_lstm_seq_bwd_args;
+int t2_lstm_seq_backward(const t2_lstm_seq_bwd_args* a, void* stream);
+
+/* General GEMM with the full descriptor (see t2_gemm); crow_mod/crow_mul permute output rows:
+ * row m is written to (m % crow_mod) * crow_mul + m / crow_mod (0 = identity). */
+typedef struct t2_gemm_args {
+    const float* A; const float* B; float* C; int M, N, K;
+    long sam, sak, sbn, sbk, ldc; int batch; long bsA, bsB, bsC;
+    float alpha, beta; const float* bias; int act; int crow_mod; long crow_mul;
+    float* ws; size_t ws_bytes; int splitk;
+} t2_gemm_args;
+int t2_gemm_ex(const t2_gemm_args* a, void* stream);
+/* out[n] = sum_m x[m*ld + n]; scratch >= 64*N floats */
+int t2_colsum(const float* x, long ld, int M, int N, float* out, float* scratch, void* stream);
+int t2_mask_btc(float* x, int B, int T, int C, const int32_t* lengths, float fill, void* stream);
+
 /* In-situ kernel timing for bench.py's roofline figures: after t2_prof_enable(n) the decoder
  * drivers bracket each per-step kernel launch with HIP events on the launch stream (up to n
  * launches); t2_prof_collect synchronises on the last event and returns total milliseconds and

@@ -101,9 +101,55 @@ class DecoderBwdArgs(C.Structure):
                 ("training", C.c_int), ("prenet_dropout", C.c_int), ("seed", C.c_uint64)]
 
 
+class ConvBnArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("K", C.c_int),
+                ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("run_mean", C.c_void_p), ("run_var", C.c_void_p),
+                ("training", C.c_int), ("eps", C.c_float), ("act", C.c_int), ("drop_p", C.c_float), ("seed", C.c_uint64),
+                ("site", C.c_uint32), ("residual", C.c_void_p),
+                ("z", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("var", C.c_void_p), ("y", C.c_void_p),
+                ("ws", C.c_void_p), ("ws_floats", C.c_size_t)]
+
+
+class ConvBnBwdArgs(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("K", C.c_int),
+                ("x", C.c_void_p), ("w", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("z", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
+                ("training", C.c_int), ("eps", C.c_float), ("act", C.c_int), ("drop_p", C.c_float), ("seed", C.c_uint64),
+                ("site", C.c_uint32), ("dy", C.c_void_p),
+                ("dw", C.c_void_p), ("dbias", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("dx", C.c_void_p), ("dx_accumulate", C.c_int), ("ws", C.c_void_p), ("ws_floats", C.c_size_t)]
+
+
+_P4 = C.c_void_p * 4
+_I4 = C.c_int * 4
+
+
+class LstmSeqArgs(C.Structure):
+    _fields_ = [("nstreams", C.c_int), ("B", C.c_int), ("T", C.c_int), ("H", C.c_int),
+                ("pre", _P4), ("w_hh", _P4), ("reverse", _I4), ("lengths", C.c_void_p),
+                ("h", _P4), ("ldh", C.c_long), ("c", _P4), ("gates", _P4)]
+
+
+class LstmSeqBwdArgs(C.Structure):
+    _fields_ = [("nstreams", C.c_int), ("B", C.c_int), ("T", C.c_int), ("H", C.c_int),
+                ("w_hh", _P4), ("reverse", _I4), ("h", _P4), ("ldh", C.c_long), ("c", _P4), ("gates", _P4),
+                ("dh", _P4), ("lddh", C.c_long), ("dpre", _P4), ("dw_hh", _P4), ("ws", C.c_void_p), ("ws_floats", C.c_size_t)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("sam", C.c_long), ("sak", C.c_long), ("sbn", C.c_long), ("sbk", C.c_long), ("ldc", C.c_long),
+                ("batch", C.c_int), ("bsA", C.c_long), ("bsB", C.c_long), ("bsC", C.c_long),
+                ("alpha", C.c_float), ("beta", C.c_float), ("bias", C.c_void_p), ("act", C.c_int),
+                ("crow_mod", C.c_int), ("crow_mul", C.c_long), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("splitk", C.c_int)]
+
+
 # every symbol include/t2amd.h declares (tests/test_abi.py checks the library exports them all)
 EXPORTS = ["t2_last_error", "t2_version", "t2_decoder_layout_query", "t2_decoder_forward", "t2_decoder_infer",
            "t2_decoder_bwd_layout_query", "t2_decoder_backward", "t2_prof_enable", "t2_prof_collect",
+           "t2_conv_bn_forward", "t2_conv_bn_backward", "t2_embedding_forward", "t2_embedding_backward",
+           "t2_lstm_seq_forward", "t2_lstm_seq_backward", "t2_gemm_ex", "t2_colsum", "t2_mask_btc",
            "t2_finalize_bct", "t2_mask_bt", "t2_gemm", "t2_rng_keep_mask", "t2_rng_normal"]
 
 _lib = None
@@ -128,6 +174,15 @@ def lib() -> C.CDLL:
         L.t2_decoder_bwd_layout_query.argtypes = [C.POINTER(Dims), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(DecoderBwdLayout)]
         L.t2_decoder_backward.argtypes = [C.POINTER(Dims), C.POINTER(DecoderWeights), C.POINTER(DecoderGrads),
                                           C.POINTER(DecoderBwdArgs), C.c_void_p]
+        L.t2_conv_bn_forward.argtypes = [C.POINTER(ConvBnArgs), C.c_void_p]
+        L.t2_conv_bn_backward.argtypes = [C.POINTER(ConvBnBwdArgs), C.c_void_p]
+        L.t2_embedding_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.t2_embedding_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.t2_lstm_seq_forward.argtypes = [C.POINTER(LstmSeqArgs), C.c_void_p]
+        L.t2_lstm_seq_backward.argtypes = [C.POINTER(LstmSeqBwdArgs), C.c_void_p]
+        L.t2_gemm_ex.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
+        L.t2_colsum.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.t2_mask_btc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p]
         L.t2_prof_enable.argtypes = [C.c_int]
         L.t2_prof_collect.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.t2_finalize_bct.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p]

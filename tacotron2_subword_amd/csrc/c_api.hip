@@ -623,6 +623,136 @@ int t2_decoder_infer(const t2_dims* dims, const t2_decoder_weights* w, const t2_
 }
 
 
+int t2_conv_bn_forward(const t2_conv_bn_args* a, void* stream) {
+    T2_REQUIRE(a, "null argument");
+    const size_t nw = (size_t)a->Cout * a->Cin * a->K;
+    T2_REQUIRE(a->ws_floats >= nw + 128 * (size_t)a->Cout, "t2_conv_bn_forward: workspace too small");
+    ConvBnFwd f{};
+    f.x = a->x; f.B = a->B; f.T = a->T; f.Cin = a->Cin; f.Cout = a->Cout; f.K = a->K;
+    f.w = a->w; f.bias = a->bias; f.gamma = a->gamma; f.beta = a->beta; f.run_mean = a->run_mean; f.run_var = a->run_var;
+    f.training = a->training; f.eps = a->eps; f.act = a->act; f.drop_p = a->drop_p; f.seed = a->seed; f.site = a->site;
+    f.residual = a->residual; f.z = a->z; f.mean = a->mean; f.invstd = a->invstd; f.var = a->var; f.y = a->y;
+    f.wperm = a->ws; f.scratch = a->ws + align4(nw);
+    return conv_bn_fwd(f, (hipStream_t)stream);
+}
+
+int t2_conv_bn_backward(const t2_conv_bn_bwd_args* a, void* stream) {
+    T2_REQUIRE(a, "null argument");
+    const size_t nw = align4((size_t)a->Cout * a->Cin * a->K), ndz = align4((size_t)a->B * a->T * a->Cout), nsc = 128 * (size_t)a->Cout;
+    T2_REQUIRE(a->ws_floats >= nw + ndz + nsc, "t2_conv_bn_backward: workspace too small");
+    ConvBnBwd f{};
+    f.x = a->x; f.B = a->B; f.T = a->T; f.Cin = a->Cin; f.Cout = a->Cout; f.K = a->K;
+    f.w = a->w; f.gamma = a->gamma; f.beta = a->beta; f.z = a->z; f.mean = a->mean; f.invstd = a->invstd;
+    f.training = a->training; f.eps = a->eps; f.act = a->act; f.drop_p = a->drop_p; f.seed = a->seed; f.site = a->site;
+    f.dy = a->dy; f.dw = a->dw; f.dbias = a->dbias; f.dgamma = a->dgamma; f.dbeta = a->dbeta;
+    f.dx = a->dx; f.dx_accumulate = a->dx_accumulate;
+    f.dz = a->ws; f.wperm = a->ws + ndz; f.scratch = a->ws + ndz + nw;
+    f.gemm_ws = a->ws + ndz + nw + nsc; f.gemm_ws_bytes = (a->ws_floats - (ndz + nw + nsc)) * sizeof(float);
+    return conv_bn_bwd(f, (hipStream_t)stream);
+}
+
+int t2_embedding_forward(const int64_t* ids, const float* table, float* out, int rows, int dim, void* stream) {
+    return embedding_fwd(reinterpret_cast<const long*>(ids), table, out, rows, dim, (hipStream_t)stream);
+}
+int t2_embedding_backward(const int64_t* ids, const float* dout, float* dtable, int rows, int dim, int vocab, void* stream) {
+    return embedding_bwd(reinterpret_cast<const long*>(ids), dout, dtable, rows, dim, vocab, (hipStream_t)stream);
+}
+
+int t2_lstm_seq_forward(const t2_lstm_seq_args* a, void* stream) {
+    T2_REQUIRE(a && a->nstreams >= 1 && a->nstreams <= kMaxLstmStreams, "t2_lstm_seq_forward: bad nstreams");
+    T2_REQUIRE(a->H % 64 == 0, "t2_lstm_seq_forward: H=%d must be a multiple of 64", a->H);
+    const int B = a->B, T = a->T, H = a->H;
+    for (int step = 0; step < T; ++step) {
+        LstmStepDesc d{};
+        d.nstreams = a->nstreams; d.B = B; d.H = H; d.drop_p = 0.f;
+        for (int s = 0; s < a->nstreams; ++s) {
+            LstmStream& st = d.st[s];
+            const int t = a->reverse[s] ? T - 1 - step : step;
+            const int tp = a->reverse[s] ? t + 1 : t - 1;            // time index processed in the previous step
+            st.pre = a->pre[s] + (long)t * B * 4 * H; st.ldpre = 4 * H;
+            if (step > 0) {
+                st.seg[0] = LstmSeg{a->h[s] + (long)tp * B * a->ldh, a->ldh, a->w_hh[s], (long)H, H};
+                st.nseg = 1;
+                st.c_prev = a->c[s] + (long)tp * B * H; st.ldc_prev = H;
+            }
+            st.gates = a->gates[s] + (long)t * B * 4 * H; st.ldgates = 4 * H;
+            st.c_out = a->c[s] + (long)t * B * H; st.ldc_out = H;
+            st.h_out = a->h[s] + (long)t * B * a->ldh; st.ldh_out = a->ldh;
+            st.lengths = a->lengths; st.t = t;
+        }
+        T2_TRY(lstm_step_fwd(d, (hipStream_t)stream));
+    }
+    return 0;
+}
+
+int t2_lstm_seq_backward(const t2_lstm_seq_bwd_args* a, void* stream) {
+    T2_REQUIRE(a && a->nstreams >= 1 && a->nstreams <= kMaxLstmStreams, "t2_lstm_seq_backward: bad nstreams");
+    const int B = a->B, T = a->T, H = a->H, ns = a->nstreams;
+    const int ks = lstm_bwd_ksplit(4 * H);
+    hipStream_t s = (hipStream_t)stream;
+    float* dc = a->ws;                                        // [ns][B*H]
+    float* part = dc + align4((size_t)ns * B * H);            // [ns][ks][B][H]
+    float* gws = part + align4((size_t)ns * ks * B * H);
+    T2_REQUIRE(a->ws_floats >= (size_t)(gws - a->ws), "t2_lstm_seq_backward: workspace too small");
+    const size_t gws_bytes = (a->ws_floats - (size_t)(gws - a->ws)) * sizeof(float);
+    for (int step = 0; step < T; ++step) {                    // reverse of the processing order
+        LstmBwdPointDesc p{};
+        p.nstreams = ns; p.B = B; p.H = H; p.drop_p = 0.f; p.first = step == 0;
+        LstmBwdGemmDesc g{};
+        g.nstreams = ns; g.B = B; g.H4 = 4 * H; g.KS = ks; g.NC = H;
+        for (int i = 0; i < ns; ++i) {
+            // processing order: forward dir t = 0..T-1, reverse dir t = T-1..0; BPTT visits it backwards
+            const int t = a->reverse[i] ? step : T - 1 - step;
+            const int tprev = a->reverse[i] ? t + 1 : t - 1;  // the step whose state entered step t
+            const bool has_prev = a->reverse[i] ? (t + 1 < T) : (t > 0);
+            LstmBwdStream& st = p.st[i];
+            st.dh1 = a->dh[i] + (long)t * B * a->lddh; st.lddh1 = a->lddh;
+            st.part = part + (size_t)i * ks * B * H; st.nparts = ks; st.part_stride = (long)B * H; st.ldpart = H; st.part_col = 0;
+            st.gates = a->gates[i] + (long)t * B * 4 * H; st.ldgates = 4 * H;
+            st.c_new = a->c[i] + (long)t * B * H; st.ldc_new = H;
+            if (has_prev) { st.c_prev = a->c[i] + (long)tprev * B * H; st.ldc_prev = H; }
+            st.dc_state = dc + (size_t)i * B * H;
+            st.dg = a->dpre[i] + (long)t * B * 4 * H; st.lddg = 4 * H;
+            g.st[i].dg = st.dg; g.st[i].lddg = 4 * H;
+            g.st[i].seg[0] = LstmBwdSeg{a->w_hh[i], (long)H, H}; g.st[i].nseg = 1;
+            g.st[i].part = part + (size_t)i * ks * B * H;
+        }
+        T2_TRY(lstm_bwd_pointwise(p, s));
+        if (step + 1 < T) T2_TRY(lstm_bwd_gemm(g, s));
+    }
+    // d(W_hh) = sum_t dpre(t)^T . h(previous processed step)
+    for (int i = 0; i < ns; ++i) {
+        if (T < 2) { T2_TRY(fill_f32(a->dw_hh[i], 0.f, (size_t)4 * H * H, s)); continue; }
+        GemmDesc w = gemm_desc();
+        const long rowsB = (long)B;
+        w.A = a->reverse[i] ? a->dpre[i] : a->dpre[i] + rowsB * 4 * H; w.sam = 1; w.sak = 4 * H;
+        w.B = a->reverse[i] ? a->h[i] + rowsB * a->ldh : a->h[i]; w.sbk = a->ldh; w.sbn = 1;
+        w.C = a->dw_hh[i]; w.ldc = H; w.M = 4 * H; w.N = H; w.K = (T - 1) * B;
+        w.ws = gws; w.ws_bytes = gws_bytes;
+        T2_TRY(gemm(w, s));
+    }
+    return 0;
+}
+
+int t2_gemm_ex(const t2_gemm_args* a, void* stream) {
+    T2_REQUIRE(a, "null argument");
+    GemmDesc g = gemm_desc();
+    g.A = a->A; g.B = a->B; g.C = a->C; g.M = a->M; g.N = a->N; g.K = a->K;
+    g.sam = a->sam; g.sak = a->sak; g.sbn = a->sbn; g.sbk = a->sbk; g.ldc = a->ldc;
+    g.batch = a->batch > 0 ? a->batch : 1; g.bsA = a->bsA; g.bsB = a->bsB; g.bsC = a->bsC;
+    g.alpha = a->alpha; g.beta = a->beta; g.bias1 = a->bias; g.act = a->act;
+    g.crow_mod = a->crow_mod; g.crow_mul = a->crow_mul;
+    g.ws = a->ws; g.ws_bytes = a->ws_bytes; g.splitk = a->splitk;
+    return gemm(g, (hipStream_t)stream);
+}
+int t2_colsum(const float* x, long ld, int M, int N, float* out, float* scratch, void* stream) {
+    return colsum(x, ld, M, N, out, nullptr, scratch, (hipStream_t)stream);
+}
+int t2_mask_btc(float* x, int B, int T, int C, const int32_t* lengths, float fill, void* stream) {
+    T2_REQUIRE(lengths, "t2_mask_btc: lengths is null");
+    return mask_btc(x, B, T, C, lengths, fill, (hipStream_t)stream);
+}
+
 int t2_prof_enable(int max_launches) {
     if (max_launches <= 0) { g_prof.on = false; return 0; }
     const size_t need = (size_t)max_launches * 2;

@@ -85,3 +85,8 @@ void t2_set_error(const char* fmt, ...);
         }                                                                                    \
     } while (0)
 #define T2_LAUNCH_CHECK() T2_CHECK_HIP(hipGetLastError())
+#define T2_TRY_RC(expr)             \
+    do {                            \
+        int rc__ = (expr);          \
+        if (rc__ != 0) return rc__; \
+    } while (0)

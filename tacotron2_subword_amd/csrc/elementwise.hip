@@ -64,6 +64,14 @@ __global__ void mask_bt_kernel(float* x, int B, int T, const int* __restrict__ l
     }
 }
 
+__global__ void mask_btc_kernel(float* x, int B, int T, int C, const int* __restrict__ lengths, float fill) {
+    const size_t n = (size_t)B * T * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / C;
+        if ((int)(r % T) >= lengths[r / T]) x[i] = fill;
+    }
+}
+
 __global__ void fill_kernel(float* p, float v, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -163,6 +171,11 @@ int transpose_btc_to_bct(const float* in, float* out, int B, int T, int C, const
 }
 int mask_bt(float* x, int B, int T, const int* lengths, float fill, hipStream_t s) {
     hipLaunchKernelGGL(mask_bt_kernel, dim3(grid_for((size_t)B * T)), dim3(256), 0, s, x, B, T, lengths, fill);
+    T2_LAUNCH_CHECK();
+    return 0;
+}
+int mask_btc(float* x, int B, int T, int C, const int* lengths, float fill, hipStream_t s) {
+    hipLaunchKernelGGL(mask_btc_kernel, dim3(grid_for((size_t)B * T * C)), dim3(256), 0, s, x, B, T, C, lengths, fill);
     T2_LAUNCH_CHECK();
     return 0;
 }

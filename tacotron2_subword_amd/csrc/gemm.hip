@@ -43,10 +43,15 @@ __device__ __forceinline__ void epilogue_store(const GemmDesc& d, float* C, int 
     *p = v;
 }
 
+// Implicit im2col for a k-tap 1-D convolution over channels-last frames X[B*T, C]: the operand is
+// the virtual matrix V[m, dk*C + ci] = X[m + dk - pad, ci] if the shifted frame stays inside the
+// same utterance (0 <= m%T + dk - pad < T), else 0.  T == 0: ordinary strided operand.
+struct ConvAddr { int T, C, pad; };
+
 // Load one operand tile (R rows x BK) into registers.  KC: k is the contiguous stride.
 template <int R, bool KC>
 __device__ __forceinline__ void load_tile(const float* __restrict__ base, long srow, long sk, int row0, int nrows,
-                                          int k0, int kend, int vec, f32x4 (&regs)[R * 4 / 256]) {
+                                          int k0, int kend, int vec, ConvAddr cv, f32x4 (&regs)[R * 4 / 256]) {
     constexpr int NQ = R * 4 / 256;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -55,23 +60,37 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ base, long s
         if (KC) {
             int row = row0 + (q >> 2), k = k0 + (q & 3) * 4;
             if (row < nrows) {
-                const float* p = base + (long)row * srow + k;
-                if (vec && k + 3 < kend) {
-                    v = *reinterpret_cast<const f32x4*>(p);
+                if (cv.T) {                                  // rows = frames m, k = dk*C + ci  (C % 4 == 0)
+                    if (k < kend) {
+                        const int dk = k / cv.C, ci = k - dk * cv.C, t = row % cv.T + dk - cv.pad;
+                        if (t >= 0 && t < cv.T) v = *reinterpret_cast<const f32x4*>(base + (long)(row + dk - cv.pad) * cv.C + ci);
+                    }
                 } else {
+                    const float* p = base + (long)row * srow + k;
+                    if (vec && k + 3 < kend) {
+                        v = *reinterpret_cast<const f32x4*>(p);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (k + j < kend) v[j] = p[j];
+                        for (int j = 0; j < 4; ++j) if (k + j < kend) v[j] = p[j];
+                    }
                 }
             }
         } else {
             int k = k0 + q / (R / 4), row = row0 + (q % (R / 4)) * 4;
             if (k < kend) {
-                const float* p = base + (long)k * sk + row;
-                if (vec && row + 3 < nrows) {
-                    v = *reinterpret_cast<const f32x4*>(p);
+                if (cv.T) {                                  // k = frames m, rows = dk*C + ci
+                    if (row < nrows) {
+                        const int dk = row / cv.C, ci = row - dk * cv.C, t = k % cv.T + dk - cv.pad;
+                        if (t >= 0 && t < cv.T) v = *reinterpret_cast<const f32x4*>(base + (long)(k + dk - cv.pad) * cv.C + ci);
+                    }
                 } else {
+                    const float* p = base + (long)k * sk + row;
+                    if (vec && row + 3 < nrows) {
+                        v = *reinterpret_cast<const f32x4*>(p);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (row + j < nrows) v[j] = p[j];
+                        for (int j = 0; j < 4; ++j) if (row + j < nrows) v[j] = p[j];
+                    }
                 }
             }
         }
@@ -125,10 +144,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    const ConvAddr cva{d.conv_a ? d.conv_T : 0, d.conv_C, d.conv_pad}, cvb{d.conv_b ? d.conv_T : 0, d.conv_C, d.conv_pad};
     f32x4 ra[BM * 4 / 256], rb[BN * 4 / 256];
     if (kbeg < kend) {
-        load_tile<BM, A_KC>(A, d.sam, d.sak, m0, d.M, kbeg, kend, g.avec, ra);
-        load_tile<BN, B_KC>(B, d.sbn, d.sbk, n0, d.N, kbeg, kend, g.bvec, rb);
+        load_tile<BM, A_KC>(A, d.sam, d.sak, m0, d.M, kbeg, kend, g.avec, cva, ra);
+        load_tile<BN, B_KC>(B, d.sbn, d.sbk, n0, d.N, kbeg, kend, g.bvec, cvb, rb);
         store_tile<BM, A_KC>(As[0], ra);
         store_tile<BN, B_KC>(Bs[0], rb);
     }
@@ -137,8 +157,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK g) {
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = k0 + BK < kend;
         if (more) {
-            load_tile<BM, A_KC>(A, d.sam, d.sak, m0, d.M, k0 + BK, kend, g.avec, ra);
-            load_tile<BN, B_KC>(B, d.sbn, d.sbk, n0, d.N, k0 + BK, kend, g.bvec, rb);
+            load_tile<BM, A_KC>(A, d.sam, d.sak, m0, d.M, k0 + BK, kend, g.avec, cva, ra);
+            load_tile<BN, B_KC>(B, d.sbn, d.sbk, n0, d.N, k0 + BK, kend, g.bvec, cvb, rb);
         }
         const float* as = As[cur] + wm * (BM / 2) + r;
         const float* bs = Bs[cur] + wn * (BN / 2) + r;
@@ -213,6 +233,12 @@ int gemm(const GemmDesc& din, hipStream_t s) {
     g.d = din;
     GemmDesc& d = g.d;
     T2_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.batch > 0, "gemm: bad shape M=%d N=%d K=%d batch=%d", d.M, d.N, d.K, d.batch);
+    if (d.conv_a || d.conv_b) {
+        T2_REQUIRE(d.conv_T > 0 && d.conv_C > 0 && d.conv_C % 4 == 0 && !(d.conv_a && d.conv_b), "gemm: bad implicit-conv operand (T=%d C=%d)", d.conv_T, d.conv_C);
+        T2_REQUIRE(d.batch == 1, "gemm: implicit-conv operands need batch == 1");
+        if (d.conv_a) { d.sam = 0; d.sak = 1; T2_REQUIRE(d.K % d.conv_C == 0 && aligned16(d.A), "gemm: conv A operand: K=%d C=%d", d.K, d.conv_C); }
+        if (d.conv_b) { d.sbk = 0; d.sbn = 1; T2_REQUIRE(d.N % d.conv_C == 0 && aligned16(d.B), "gemm: conv B operand: N=%d C=%d", d.N, d.conv_C); }
+    }
     T2_REQUIRE(d.sam == 1 || d.sak == 1, "gemm: A needs one unit stride (sam=%ld sak=%ld)", d.sam, d.sak);
     T2_REQUIRE(d.sbn == 1 || d.sbk == 1, "gemm: B needs one unit stride (sbn=%ld sbk=%ld)", d.sbn, d.sbk);
     T2_REQUIRE(d.drop_p == 0.f || (d.batch == 1 && (long)d.M * d.N < (1l << 32)), "gemm: dropout epilogue needs batch==1 and M*N < 2^32");

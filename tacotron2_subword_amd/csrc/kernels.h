@@ -23,6 +23,8 @@ struct GemmDesc {
     uint32_t drop_base, drop_mstride;             // drop_mstride 0 -> N
     float* ws; size_t ws_bytes;                   // split-K scratch (nullable -> no split)
     int splitk;                                   // 0 = choose automatically
+    int conv_a, conv_b, conv_T, conv_C, conv_pad; // implicit im2col operand (gemm.hip ConvAddr): A rows / B k-rows are
+                                                  // frames of X[B*T, C], the other index is dk*C + ci
     int crow_mod; long crow_mul;                  // output row = (m % crow_mod) * crow_mul + m / crow_mod (0 = identity):
                                                   // writes time-major rows (t,b) in batch-major order (b,t) or back
 };
@@ -124,6 +126,33 @@ struct AttnBwdStream {
 struct AttnBwdDesc { AttnBwdStream st[2]; int nstreams; int B, A, E; int first; };
 int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s);
 
+// ------------------------------------------------------------------ conv + BN stacks, embedding (conv.hip)
+struct ConvBnFwd {
+    const float* x; int B, T, Cin, Cout, K;      // x: [B*T, Cin] channels-last frames
+    const float* w; const float* bias;           // [Cout,Cin,K] (reference layout), [Cout]
+    const float* gamma; const float* beta; float* run_mean; float* run_var;   // BatchNorm1d; running stats updated iff training
+    int training; float eps; int act; float drop_p; uint64_t seed; uint32_t site;
+    const float* residual;                       // optional [B*T, Cout] added after dropout
+    float* z; float* mean; float* invstd; float* var;   // saved: conv+bias output [B*T,Cout], batch (or running) stats [Cout]
+    float* y;                                    // [B*T, Cout]
+    float* wperm; float* scratch;                // [Cout*Cin*K], [128*Cout]
+};
+int conv_bn_fwd(const ConvBnFwd& a, hipStream_t s);
+struct ConvBnBwd {
+    const float* x; int B, T, Cin, Cout, K;
+    const float* w; const float* gamma; const float* beta;
+    const float* z; const float* mean; const float* invstd;
+    int training; float eps; int act; float drop_p; uint64_t seed; uint32_t site;
+    const float* dy;                             // [B*T, Cout]
+    float* dz;                                   // scratch [B*T, Cout]
+    float* dw; float* dbias; float* dgamma; float* dbeta;
+    float* dx; int dx_accumulate;                // [B*T, Cin], nullable
+    float* wperm; float* scratch; float* gemm_ws; size_t gemm_ws_bytes;
+};
+int conv_bn_bwd(const ConvBnBwd& a, hipStream_t s);
+int embedding_fwd(const long* ids, const float* table, float* out, int rows, int D, hipStream_t s);
+int embedding_bwd(const long* ids, const float* dout, float* dtable, int rows, int D, int vocab, hipStream_t s);
+
 // ------------------------------------------------------------------ elementwise (elementwise.hip)
 int rng_keep_mask(uint64_t seed, uint32_t site, uint32_t n, float p, uint8_t* out, hipStream_t s);
 int rng_normal(uint64_t seed, uint32_t site, uint32_t n, float* out, hipStream_t s);
@@ -132,6 +161,8 @@ int teacher_inputs(const float* mel, float* X, int B, int M, int T, hipStream_t 
 // out[b,c,t] = in[b,t,c] with optional padding fill for t >= lengths[b]
 int transpose_btc_to_bct(const float* in, float* out, int B, int T, int C, const int* lengths, float fill, hipStream_t s);
 int mask_bt(float* x, int B, int T, const int* lengths, float fill, hipStream_t s);
+// x[b,t,:] = fill for t >= lengths[b]   (x is [B,T,C])
+int mask_btc(float* x, int B, int T, int C, const int* lengths, float fill, hipStream_t s);
 int fill_f32(float* p, float v, size_t n, hipStream_t s);
 // out[r2, r1, :] = in[r1, r2, :]   ([R1,R2,W] -> [R2,R1,W])
 int permute_rows(const float* in, float* out, int R1, int R2, int W, hipStream_t s);

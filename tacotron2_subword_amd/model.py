@@ -2,20 +2,23 @@
 ``state_dict`` keys and call signatures (``BERT_Tacotron2.parse_batch / forward / inference``),
 with the decoder hot loop running in the hand-written HIP library behind the C ABI.
 
-What runs where (round 1):
+What runs where:
   * Decoder (both prenets, both attention LSTMs, SMA / LSA attention, decoder LSTM, mel/gate
-    projections; teacher-forced forward + backward, autoregressive inference): HIP kernels.
-  * Encoder conv/BN/BiLSTM stacks, linear converters, postnet conv/BN stack: torch ops on the
-    GPU for now (marked INTERIM below; they are the next rows to move into csrc/).
+    projections; teacher-forced forward + backward, autoregressive inference): fused HIP drivers.
+  * Embeddings, encoder conv/BN stacks, BiLSTMs, linear converters, postnet conv/BN stack:
+    HIP building blocks (blocks.py -> conv.hip, lstm.hip, gemm.hip), forward and backward.
+  * torch is used for tensor storage, autograd bookkeeping, a few layout copies (cat / transpose)
+    and the loss reductions.
+Activations are channels-last [B,T,C] inside; the reference's [B,C,T] appears only at the API.
 There is no CPU path: calling forward() with CPU tensors raises.
 """
 from math import sqrt
 
 import torch
 from torch import nn
-from torch.nn import functional as F
 
 from . import _lib as L
+from . import blocks
 from . import ops
 from .attention import LocationSensitiveAttention, StepwiseMonotonicAttention
 from .layers import ConvNorm, LinearNorm
@@ -32,16 +35,6 @@ class Prenet(nn.Module):
         self.layers = nn.ModuleList([LinearNorm(i, o, bias=False) for i, o in zip(ins, sizes)])
 
 
-def _conv_bn_stack(x, blocks, acts, p_drop, training):
-    """INTERIM (torch ops): conv1d -> BatchNorm1d -> activation -> dropout, block by block."""
-    for block, act in zip(blocks, acts):
-        x = block(x)
-        if act is not None:
-            x = act(x)
-        x = F.dropout(x, p_drop, training)
-    return x
-
-
 class Postnet(nn.Module):
     """model.py:27-70: five Conv1d(k=5)+BatchNorm1d blocks, tanh on all but the last."""
 
@@ -56,9 +49,17 @@ class Postnet(nn.Module):
                          w_init_gain="tanh" if i < n - 1 else "linear"),
                 nn.BatchNorm1d(dims[i + 1])))
 
-    def forward(self, x):
+    def forward_btc(self, x_btc, seed, residual=True):
+        """x [B,T,n_mel] channels-last -> x + postnet(x) (model.py:557-558) as one fused stack."""
         n = len(self.convolutions)
-        return _conv_bn_stack(x, self.convolutions, [torch.tanh] * (n - 1) + [None], 0.5, self.training)
+        layers = [(blk[0].conv, blk[1]) for blk in self.convolutions]
+        return blocks.conv_bn_stack(x_btc, layers, [blocks.ACT_TANH] * (n - 1) + [blocks.ACT_NONE], training=self.training,
+                                    drop_p=0.5, seed=seed, site0=L.SITE["POSTNET0"], residual=residual)
+
+    def forward(self, x):
+        """Reference signature: [B,n_mel,T] -> [B,n_mel,T] (without the residual)."""
+        y = self.forward_btc(x.transpose(1, 2).contiguous(), _next_seed(self), residual=False)
+        return y.transpose(1, 2)
 
 
 class Encoder(nn.Module):
@@ -73,21 +74,40 @@ class Encoder(nn.Module):
             for _ in range(hparams.encoder_n_convolutions)])
         self.lstm = nn.LSTM(E, int(E / 2), 1, batch_first=True, bidirectional=True)
 
-    def _convs(self, x):
-        return _conv_bn_stack(x, self.convolutions, [F.relu] * len(self.convolutions), 0.5, self.training).transpose(1, 2)
+    def forward_btc(self, x_btc, input_lengths, site0, seed):
+        """x [B,T,E] channels-last embedded input -> [B,T,E] (conv stack + packed / unpacked BiLSTM)."""
+        layers = [(blk[0].conv, blk[1]) for blk in self.convolutions]
+        h = blocks.conv_bn_stack(x_btc, layers, [blocks.ACT_RELU] * len(layers), training=self.training, drop_p=0.5,
+                                 seed=seed, site0=site0)
+        return blocks.bilstm(h, input_lengths, self.lstm)
 
     def forward(self, x, input_lengths):
-        x = self._convs(x)
-        packed = nn.utils.rnn.pack_padded_sequence(x, input_lengths.cpu(), batch_first=True, enforce_sorted=False)
-        self.lstm.flatten_parameters()
-        out, _ = self.lstm(packed)
-        out, _ = nn.utils.rnn.pad_packed_sequence(out, batch_first=True)
-        return out
+        """Reference signature: x [B,E,T] (model.py:97-114)."""
+        return self.forward_btc(x.transpose(1, 2).contiguous(), input_lengths, L.SITE["ENC0"], _next_seed(self))
 
     def inference(self, x):
-        self.lstm.flatten_parameters()
-        out, _ = self.lstm(self._convs(x))
-        return out
+        return self.forward_btc(x.transpose(1, 2).contiguous(), None, L.SITE["ENC0"], _next_seed(self))
+
+
+def _next_seed(module):
+    """Per-call dropout seed: (hparams.seed, call counter, rank) -> 64-bit."""
+    module._t2_calls = getattr(module, "_t2_calls", 0) + 1
+    rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+    return ((getattr(module, "base_seed", 1234) * 1000003 + module._t2_calls) * 64 + rank) & ((1 << 63) - 1)
+
+
+class _FinalizeFn(torch.autograd.Function):
+    """[B,T,C] -> [B,C,T] with frames >= length filled (parse_decoder_outputs + parse_output,
+    model.py:290-320,531-541).  The reference fills in place on .data, i.e. the fill does not block
+    gradients: backward is the plain transpose."""
+
+    @staticmethod
+    def forward(ctx, x_btc, lengths, fill):
+        return ops.finalize_bct(x_btc.contiguous(), lengths, fill)
+
+    @staticmethod
+    def backward(ctx, d):
+        return d.transpose(1, 2).contiguous(), None, None
 
 
 class _DecoderFn(torch.autograd.Function):
@@ -169,18 +189,16 @@ class Decoder(nn.Module):
         return [sd[k] for k in self._param_keys()]
 
     def _next_seed(self):
-        self._calls += 1
-        rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
-        return (self.base_seed * 1000003 + self._calls) * 64 + rank
+        return _next_seed(self)
 
     def _weights(self):
         P = {"decoder." + k: v.detach() for k, v in self.named_parameters()}
         return P, L.decoder_weights(P, self.dims.attention_kind)
 
     # -- reference surface -----------------------------------------------------------------
-    def forward(self, memory, embeddings, decoder_inputs, memory_lengths, bert_lengths):
-        """Decoder.forward (model.py:392-428): returns mel [B,n_mel,T], gate [B,T], align [B,T,Tin],
-        align_bert [B,T,Tsub]."""
+    def forward(self, memory, embeddings, decoder_inputs, memory_lengths, bert_lengths, channels_last=False):
+        """Decoder.forward (model.py:392-428): returns mel [B,n_mel,T] ([B,T,n_mel] if channels_last),
+        gate [B,T], align [B,T,Tin], align_bert [B,T,Tsub]."""
         cfg = dict(decoder=self, keys=self._param_keys(), training=self.training, prenet_dropout=self.prenet_dropout,
                    seed=self._next_seed())
         if self.dims.attention_kind != L.ATTN_SMA and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -188,9 +206,9 @@ class Decoder(nn.Module):
                                       "(forward / inference are); use torch.no_grad() or StepwiseMonotonicAttention")
         mel, gate, al, alb = _DecoderFn.apply(memory, embeddings, decoder_inputs, memory_lengths, bert_lengths, cfg,
                                               *self._params())
-        return mel.transpose(1, 2), gate, al, alb
+        return (mel if channels_last else mel.transpose(1, 2)), gate, al, alb
 
-    def inference(self, memory, embeddings):
+    def inference(self, memory, embeddings, channels_last=False):
         """Decoder.inference (model.py:430-492) for any batch size; per-item stop rule of SURVEY §8a A17.
         Returns mel [B,n_mel,T'], gate [B,T',1], align, align_bert, INFER_FLAG."""
         P, W = self._weights()
@@ -202,7 +220,8 @@ class Decoder(nn.Module):
         flag = bool((stop >= 0).all())
         n = int(stop.max()) + 1 if flag else steps
         self.last_stop_index = stop
-        return (dp.mel[:, :n].transpose(1, 2), dp.gate[:, :n].unsqueeze(-1), dp.align[:, :n], dp.align_sub[:, :n], flag)
+        mel = dp.mel[:, :n]
+        return ((mel if channels_last else mel.transpose(1, 2)), dp.gate[:, :n].unsqueeze(-1), dp.align[:, :n], dp.align_sub[:, :n], flag)
 
 
 class BERT_Tacotron2(nn.Module):
@@ -244,30 +263,44 @@ class BERT_Tacotron2(nn.Module):
             outputs[2].data.masked_fill_(mask, 1e3)
         return outputs
 
-    def _front(self, ids, lengths, cls, sub):
+    def _front(self, ids, lengths, cls, sub, seed):
+        """embedding -> encoder -> cat CLS -> linear converter (model.py:546-554 / 563-572), channels-last."""
         emb, enc, conv = ((self.embedding_sub, self.encoder_sub, self.linear_converter_sub) if sub
                           else (self.embedding, self.encoder, self.linear_converter))
-        x = emb(ids).transpose(1, 2)
-        h = enc.inference(x) if lengths is None else enc(x, lengths)
-        return conv(torch.cat([h, cls[:, :h.size(1)]], 2))
+        x = blocks.embedding(ids, emb.weight)                                   # [B,T,E]
+        h = enc.forward_btc(x, lengths, L.SITE["ENCSUB0" if sub else "ENC0"], seed)
+        cat = torch.cat([h, cls[:, :h.size(1)]], 2)
+        return blocks.linear(cat, conv.linear_layer.weight, conv.linear_layer.bias)
 
     def forward(self, inputs):
         text, tl, bl, mels, _, ol, sub_ids, pcls, bcls = inputs
         tl, bl, ol = tl.data, bl.data, ol.data
-        memory = self._front(text, tl, pcls, False)
-        memory_sub = self._front(sub_ids, bl, bcls, True)
-        mel, gate, al, alb = self.decoder(memory, memory_sub, mels, tl, bl)
-        mel = mel.contiguous()          # the tensor the postnet saves AND parse_output masks in place
-        post = mel + self.postnet(mel)
-        return self.parse_output([mel, post, gate, al, alb], ol)
+        seed = _next_seed(self)
+        memory = self._front(text, tl, pcls, False, seed)
+        memory_sub = self._front(sub_ids, bl, bcls, True, seed)
+        mel_btc, gate, al, alb = self.decoder(memory, memory_sub, mels, tl, bl, channels_last=True)
+        post_btc = self.postnet.forward_btc(mel_btc, seed)                      # mel + postnet(mel), [B,T,n_mel]
+        if self.mask_padding and ol is not None:
+            mel = _FinalizeFn.apply(mel_btc, ol, 0.0)
+            post = _FinalizeFn.apply(post_btc, ol, 0.0)
+            gate = gate.clone()                                                 # keep the decoder's own buffer intact
+            ops.mask_bt_(gate.data, ol, 1e3)
+            # reference quirk (model.py:537): the fill happens in place on the tensor the postnet's first conv
+            # saved as its input, so that conv's weight gradient sees the masked mel
+            ops.mask_btc_(mel_btc.data, ol, 0.0)
+        else:
+            mel = _FinalizeFn.apply(mel_btc, None, 0.0)
+            post = _FinalizeFn.apply(post_btc, None, 0.0)
+        return [mel, post, gate, al, alb]
 
     def inference(self, inputs, embeddings, phoneme_embeddings_cls, bert_embeddings_cls):
-        memory = self._front(inputs, None, phoneme_embeddings_cls, False)
-        memory_sub = self._front(embeddings, None, bert_embeddings_cls, True)
-        mel, gate, al, alb, flag = self.decoder.inference(memory, memory_sub)
-        mel = mel.contiguous()
-        post = mel + self.postnet(mel)
-        return self.parse_output([mel, post, gate, al, alb, flag])
+        seed = _next_seed(self)
+        memory = self._front(inputs, None, phoneme_embeddings_cls, False, seed)
+        memory_sub = self._front(embeddings, None, bert_embeddings_cls, True, seed)
+        mel_btc, gate, al, alb, flag = self.decoder.inference(memory, memory_sub, channels_last=True)
+        mel_btc = mel_btc.contiguous()
+        post_btc = self.postnet.forward_btc(mel_btc, seed)
+        return [ops.finalize_bct(mel_btc, None, 0.0), ops.finalize_bct(post_btc, None, 0.0), gate, al, alb, flag]
 
 
 class Tacotron2(nn.Module):

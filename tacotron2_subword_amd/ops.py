@@ -126,3 +126,10 @@ def mask_bt_(x: torch.Tensor, lengths: torch.Tensor, fill: float) -> torch.Tenso
     ln = _i32(lengths)
     L.check(L.lib().t2_mask_bt(L.ptr(x), x.shape[0], x.shape[1], L.ptr(ln), fill, L.stream()))
     return x
+
+
+def mask_btc_(x: torch.Tensor, lengths: torch.Tensor, fill: float) -> torch.Tensor:
+    """x[b,t,:] = fill for t >= lengths[b], in place (x: [B,T,C])."""
+    ln = _i32(lengths)
+    L.check(L.lib().t2_mask_btc(L.ptr(x), x.shape[0], x.shape[1], x.shape[2], L.ptr(ln), fill, L.stream()))
+    return x

@@ -1,0 +1,129 @@
+"""GPU parity of the encoder / postnet building blocks (conv+BN+act+dropout stack, BiLSTM with
+packed-sequence semantics, embedding, linear) against the CPU oracle functions and their autograd."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import tacotron2_oracle as O
+
+from helpers import maxabs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from tacotron2_subword_amd import _lib as L
+    from tacotron2_subword_amd import blocks, ops
+    return L, blocks, ops
+
+
+def rel(a, ref):
+    return maxabs(a, ref) / max(float(ref.abs().max()), 1e-6)
+
+
+def test_linear_and_embedding(env):
+    L, blocks, ops = env
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 7, 40, generator=g, requires_grad=True)
+    W = torch.randn(24, 40, generator=g, requires_grad=True)
+    b = torch.randn(24, generator=g, requires_grad=True)
+    R = torch.randn(3, 7, 24, generator=g)
+    (F.linear(x, W, b) * R).sum().backward()
+    xd, Wd, bd = (t.detach().cuda().requires_grad_(True) for t in (x, W, b))
+    y = blocks.linear(xd, Wd, bd)
+    assert maxabs(y, F.linear(x, W, b)) < 1e-4
+    (y * R.cuda()).sum().backward()
+    assert rel(xd.grad, x.grad) < 1e-4 and rel(Wd.grad, W.grad) < 1e-4 and rel(bd.grad, b.grad) < 1e-4
+    ids = torch.randint(0, 11, (4, 9), generator=g)
+    tab = torch.randn(11, 16, generator=g, requires_grad=True)
+    R2 = torch.randn(4, 9, 16, generator=g)
+    (F.embedding(ids, tab) * R2).sum().backward()
+    tabd = tab.detach().cuda().requires_grad_(True)
+    e = blocks.embedding(ids.cuda(), tabd)
+    assert maxabs(e, F.embedding(ids, tab)) == 0.0
+    (e * R2.cuda()).sum().backward()
+    assert rel(tabd.grad, tab.grad) < 1e-5
+
+
+@pytest.mark.parametrize("training", [False, True])
+@pytest.mark.parametrize("kind", ["postnet", "encoder"])
+def test_conv_bn_stack_vs_oracle(env, kind, training):
+    L, blocks, ops = env
+    g = torch.Generator().manual_seed(3)
+    B, T = 3, 17
+    if kind == "postnet":
+        chans, acts, tacts, site0, res = [8, 32, 32, 8], [2, 2, 0], [torch.tanh, torch.tanh, None], L.SITE["POSTNET0"], True
+    else:
+        chans, acts, tacts, site0, res = [32, 32, 32], [1, 1], [F.relu, F.relu], L.SITE["ENC0"], False
+    n = len(acts)
+    convs = [torch.nn.Conv1d(chans[i], chans[i + 1], 5, padding=2) for i in range(n)]
+    bns = [torch.nn.BatchNorm1d(chans[i + 1]) for i in range(n)]
+    for bn in bns:
+        bn.weight.data.uniform_(0.5, 1.5, generator=g); bn.bias.data.uniform_(-0.2, 0.2, generator=g)
+        bn.running_mean.uniform_(-0.1, 0.1, generator=g); bn.running_var.uniform_(0.5, 1.5, generator=g)
+    x = torch.randn(B, chans[0], T, generator=g, requires_grad=True)             # reference layout [B,C,T]
+    seed = 4242
+    keep = [ops.rng_keep_mask(seed, site0 + i, B * T * chans[i + 1], 0.5).view(B, T, chans[i + 1]).float().cpu().permute(0, 2, 1)
+            for i in range(n)] if training else [None] * n
+    # oracle: the same op sequence as model.py:65-70 / :98-99 with replayed masks
+    P, stats = {}, {}
+    for i in range(n):
+        P[f"s.{i}.0.conv.weight"], P[f"s.{i}.0.conv.bias"] = convs[i].weight, convs[i].bias
+        for k in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked"):
+            P[f"s.{i}.1.{k}"] = getattr(bns[i], k)
+    h = x
+    for i in range(n):
+        h = O.conv_bn(h, P, f"s.{i}.0", f"s.{i}.1", training, stats)
+        if tacts[i] is not None:
+            h = tacts[i](h)
+        h = O._drop(h, keep[i], 0.5)
+    if res:
+        h = h + x
+    R = torch.randn(h.shape, generator=g)
+    (h * R).sum().backward()
+    # HIP
+    import copy
+    dconvs = [copy.deepcopy(c).cuda() for c in convs]
+    dbns = [copy.deepcopy(b).cuda() for b in bns]
+    for m_ in dconvs + dbns:
+        m_.zero_grad()
+    xd = x.detach().permute(0, 2, 1).contiguous().cuda().requires_grad_(True)   # [B,T,C]
+    y = blocks.conv_bn_stack(xd, list(zip(dconvs, dbns)), acts, training=training, drop_p=0.5, seed=seed, site0=site0, residual=res)
+    assert maxabs(y.permute(0, 2, 1), h) < 2e-4
+    (y * R.permute(0, 2, 1).contiguous().cuda()).sum().backward()
+    assert rel(xd.grad.permute(0, 2, 1), x.grad) < 5e-4
+    for i in range(n):
+        assert rel(dconvs[i].weight.grad, convs[i].weight.grad) < 5e-4, i
+        assert rel(dconvs[i].bias.grad, convs[i].bias.grad) < 5e-4 or float(convs[i].bias.grad.abs().max()) < 1e-4, i
+        assert rel(dbns[i].weight.grad, bns[i].weight.grad) < 5e-4, i
+        assert rel(dbns[i].bias.grad, bns[i].bias.grad) < 5e-4, i
+        if training:
+            assert maxabs(dbns[i].running_mean, stats[f"s.{i}.1.running_mean"]) < 1e-5
+            assert maxabs(dbns[i].running_var, stats[f"s.{i}.1.running_var"]) < 1e-5
+            assert int(dbns[i].num_batches_tracked) == int(bns[i].num_batches_tracked) + 1
+
+
+@pytest.mark.parametrize("packed", [True, False])
+def test_bilstm_vs_oracle(env, packed):
+    L, blocks, ops = env
+    g = torch.Generator().manual_seed(5)
+    B, T, E = 5, 11, 64
+    lstm = torch.nn.LSTM(E, E // 2, 1, batch_first=True, bidirectional=True)
+    x = torch.randn(B, T, E, generator=g, requires_grad=True)
+    lengths = torch.tensor([11, 9, 9, 4, 1]) if packed else None
+    P = {"l." + k: v for k, v in lstm.named_parameters()}
+    out = O.bilstm(x, lengths, P, "l")
+    R = torch.randn(out.shape, generator=g)
+    (out * R).sum().backward()
+    import copy
+    dl = copy.deepcopy(lstm).cuda()
+    dl.zero_grad()
+    xd = x.detach().cuda().requires_grad_(True)
+    y = blocks.bilstm(xd, None if lengths is None else lengths.cuda(), dl)
+    assert maxabs(y, out) < 1e-4
+    (y * R.cuda()).sum().backward()
+    assert rel(xd.grad, x.grad) < 3e-4
+    for (k, p), (_, q) in zip(lstm.named_parameters(), dl.named_parameters()):
+        assert rel(q.grad, p.grad) < 3e-4, k

@@ -40,21 +40,13 @@ def test_forward_eval_vs_golden(att, name):
         assert maxabs(v, g[k]) < TOL, k
 
 
-def test_backward_eval_mode_vs_oracle_autograd(monkeypatch):
-    """Whole-model gradients (encoders, converters, decoder, postnet) with every source of
-    randomness off (BN running statistics, no dropout, no noise): the HIP decoder backward inside
-    torch autograd vs the oracle's autograd.  (The interim torch BiLSTM needs train mode for its
-    backward, so the module is in train mode with BN / decoder in eval and dropout patched out.)"""
+def test_backward_eval_mode_vs_oracle_autograd():
+    """Whole-model gradients (embeddings, encoders, converters, decoder, postnet) in eval mode (BN
+    running statistics, no dropout, no noise): HIP backward of every block vs the oracle's autograd."""
     att = SMA
     hp = hp_for(att)
     B, Tin, Tsub, T = 3, 13, 8, 12
-    m, hps = build_model(att, train=True)
-    import tacotron2_subword_amd.model as M
-    monkeypatch.setattr(M.F, "dropout", lambda x, p=0.5, training=True, inplace=False: x)
-    for mod in m.modules():
-        if isinstance(mod, torch.nn.BatchNorm1d):
-            mod.eval()
-    m.decoder.eval()
+    m, hps = build_model(att, train=False)
     from tacotron2_subword_amd.loss_function import Tacotron2Loss
     batch = recipe.make_batch(hp, B, Tin, Tsub, T)
     x, y = m.parse_batch(batch)
@@ -120,3 +112,62 @@ def test_training_step_runs_and_is_finite():
     for k, v in model.named_parameters():
         moved = not torch.equal(v.detach(), before[k])
         assert moved == (not k.startswith("decoder.decoder_rnn_bert")), k
+
+
+def test_training_mode_full_model_vs_oracle():
+    """Training mode end to end: BN batch statistics, conv/LSTM-state/prenet dropout and SMA noise drawn
+    by the HIP RNG (exported through the C ABI and replayed through the oracle), loss, every parameter
+    gradient, and the BN running-statistics update."""
+    from tacotron2_subword_amd import _lib as L
+    from tacotron2_subword_amd import ops
+    from tacotron2_subword_amd.loss_function import Tacotron2Loss
+    hp = hp_for(SMA)
+    B, Tin, Tsub, T = 3, 13, 8, 12
+    m, hps = build_model(SMA, train=True)
+    m.decoder.prenet_dropout = True
+    m._t2_calls, m.decoder._t2_calls = 0, 0
+    seed = ((1234 * 1000003 + 1) * 64) & ((1 << 63) - 1)
+    batch = recipe.make_batch(hp, B, Tin, Tsub, T)
+    x, y = m.parse_batch(batch)
+    out = m(x)
+    loss = Tacotron2Loss()(out, y, x)[0]
+    loss.backward()
+    # the bits the kernels drew, in the oracle's layouts
+    S, E, Pn, Ha, Hd, M = L.SITE, 512, 256, 1024, 1024, 80
+    km = lambda site, p, *shape: ops.rng_keep_mask(seed, site, int(np.prod(shape)), p).view(*shape).float().cpu()
+    bct = lambda t: t.permute(0, 2, 1).contiguous()
+    rnd = dict(enc_keep=[bct(km(S["ENC0"] + i, 0.5, B, Tin, E)) for i in range(3)],
+               encsub_keep=[bct(km(S["ENCSUB0"] + i, 0.5, B, Tsub, E)) for i in range(3)],
+               post_keep=[bct(km(S["POSTNET0"] + i, 0.5, B, T, M if i == 4 else 512)) for i in range(5)],
+               prenet_keep=[km(S["PRENET1"], 0.5, T, B, Pn), km(S["PRENET2"], 0.5, T, B, Pn)],
+               prenet_bert_keep=[km(S["PRENET1_SUB"], 0.5, T, B, Pn), km(S["PRENET2_SUB"], 0.5, T, B, Pn)],
+               att_h_keep=km(S["ATT_H"], 0.1, T, B, Ha), att_c_keep=km(S["ATT_C"], 0.1, T, B, Ha),
+               att_h_bert_keep=km(S["ATT_H_SUB"], 0.1, T, B, Ha), att_c_bert_keep=km(S["ATT_C_SUB"], 0.1, T, B, Ha),
+               dec_h_keep=km(S["DEC_H"], 0.1, T, B, Hd), dec_c_keep=km(S["DEC_C"], 0.1, T, B, Hd),
+               sma_noise=ops.rng_normal(seed, S["NOISE"], B * T * Tin).view(T, B, Tin).cpu(),
+               sma_noise_bert=ops.rng_normal(seed, S["NOISE_SUB"], B * T * Tsub).view(T, B, Tsub).cpu())
+    P = recipe.make_weights(hp)
+    for k, v in P.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    xo, yo = recipe.parse_batch(batch)
+    stats = {}
+    oo = O.forward(P, hp, xo, training=True, rnd=rnd, new_stats=stats)
+    for k, a, b in zip(("mel", "mel_postnet", "gate", "align", "align_bert"), out, oo):
+        assert maxabs(a, b.detach()) < 2e-4, k
+    lo = O.loss(oo, yo)[0]
+    lo.backward()
+    assert abs(float(loss.detach()) - float(lo.detach())) < 1e-5
+    bad = {}
+    for k, p in m.named_parameters():
+        ref = P[k].grad
+        if ref is None:
+            assert p.grad is None, k
+            continue
+        err = maxabs(p.grad, ref) / max(float(ref.abs().max()), 1e-7)
+        if not err < 1e-3:
+            bad[k] = err
+    assert not bad, bad
+    sd = m.state_dict()
+    for k, v in stats.items():
+        assert maxabs(sd[k].float(), v.float()) < 1e-5, k
