@@ -187,8 +187,9 @@ def main():
         "config": {"workload": f"BERT_Tacotron2 default hparams (SMA), full training iteration fwd+loss+bwd+clip+Adam, "
                                f"B={B}/GPU, {Tin} phones, {Tsub} sub-word tokens, {Tn} frames, 80-mel",
                    "global_batch": world * B, "frames_per_item": Tn, "parallelism": f"dp{world}",
-                   "hip_kernels": "decoder fwd+bwd (prenets, attention LSTMs, SMA, decoder LSTM, projections)",
-                   "interim_torch_ops": "encoder conv/BN/BiLSTM, postnet conv/BN, loss, clip, Adam"},
+                   "hip_kernels": "embeddings, encoder conv/BN + BiLSTM, converters, decoder (prenets, attention LSTMs, SMA, "
+                                  "decoder LSTM, projections), postnet conv/BN: forward and backward",
+                   "torch_ops": "loss reductions, clip_grad_norm_, Adam, cat/transpose copies"},
         "loss": round(loss_val, 5),
         "roofline": roof, "kernels": kernels,
     }

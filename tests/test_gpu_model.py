@@ -62,7 +62,7 @@ def test_backward_eval_mode_vs_oracle_autograd():
     oo = O.forward(P, hp, xo, training=False)
     lo = O.loss(oo, yo)[0]
     lo.backward()
-    assert abs(float(loss) - float(lo)) < 1e-5
+    assert abs(float(loss.detach()) - float(lo.detach())) < 1e-5
     bad = {}
     for k, p in m.named_parameters():
         ref = P[k].grad
@@ -164,7 +164,8 @@ def test_training_mode_full_model_vs_oracle():
         if ref is None:
             assert p.grad is None, k
             continue
-        err = maxabs(p.grad, ref) / max(float(ref.abs().max()), 1e-7)
+        # conv biases feeding a train-mode BatchNorm have a mathematically zero gradient: absolute floor
+        err = maxabs(p.grad, ref) / max(float(ref.abs().max()), 1e-4)
         if not err < 1e-3:
             bad[k] = err
     assert not bad, bad
