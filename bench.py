@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--tsub", type=int, default=60)
     ap.add_argument("--frames", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="GEMM operand type: f32 = exact fp32 (parity path); bf16 = bf16 operands, fp32 accumulate/state")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -107,6 +109,7 @@ def main():
     from tacotron2_subword_amd.hparams import create_hparams
     from tacotron2_subword_amd import train as T
 
+    L.set_precision(a.dtype)
     hp = create_hparams()
     hp.distributed_run = world > 1
     if world > 1:
@@ -183,7 +186,7 @@ def main():
     out = {
         "metric": "mel_frames_per_sec_train", "value": round(frames / dt, 1), "unit": "mel-frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 2),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": f"BERT_Tacotron2 default hparams (SMA), full training iteration fwd+loss+bwd+clip+Adam, "
                                f"B={B}/GPU, {Tin} phones, {Tsub} sub-word tokens, {Tn} frames, 80-mel",
                    "global_batch": world * B, "frames_per_item": Tn, "parallelism": f"dp{world}",

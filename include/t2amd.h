@@ -39,6 +39,11 @@ enum {
 
 const char* t2_last_error(void);
 int t2_version(void);
+/* Arithmetic type of the GEMM operands: 0 = fp32 (exact fp32 fma chains; the parity path, default),
+ * 1 = bf16 operands with fp32 accumulation for the large GEMMs (fp32 storage, converted while
+ * staging); recurrent state, BatchNorm statistics and attention recurrences stay fp32. */
+int t2_set_precision(int mode);
+int t2_get_precision(void);
 
 /* Model dimensions (hparams.py:55-95). */
 typedef struct t2_dims {

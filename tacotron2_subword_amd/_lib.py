@@ -146,7 +146,7 @@ class GemmArgs(C.Structure):
 
 
 # every symbol include/t2amd.h declares (tests/test_abi.py checks the library exports them all)
-EXPORTS = ["t2_last_error", "t2_version", "t2_decoder_layout_query", "t2_decoder_forward", "t2_decoder_infer",
+EXPORTS = ["t2_last_error", "t2_version", "t2_set_precision", "t2_get_precision", "t2_decoder_layout_query", "t2_decoder_forward", "t2_decoder_infer",
            "t2_decoder_bwd_layout_query", "t2_decoder_backward", "t2_prof_enable", "t2_prof_collect",
            "t2_conv_bn_forward", "t2_conv_bn_backward", "t2_embedding_forward", "t2_embedding_backward",
            "t2_lstm_seq_forward", "t2_lstm_seq_backward", "t2_gemm_ex", "t2_colsum", "t2_mask_btc",
@@ -306,3 +306,12 @@ def prof_collect() -> dict:
     ms, cnt = (C.c_double * n)(), (C.c_int * n)()
     check(lib().t2_prof_collect(n, ms, cnt))
     return {k: (ms[i], cnt[i]) for i, k in enumerate(PROF_KINDS)}
+
+
+def set_precision(mode: str) -> None:
+    """"f32": exact fp32 GEMMs (parity path, default).  "bf16": bf16 operands / fp32 accumulate for large GEMMs."""
+    check(lib().t2_set_precision({"f32": 0, "fp32": 0, "bf16": 1}[mode]))
+
+
+def get_precision() -> str:
+    return "bf16" if lib().t2_get_precision() == 1 else "f32"

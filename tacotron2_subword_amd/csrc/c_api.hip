@@ -423,6 +423,12 @@ extern "C" {
 
 const char* t2_last_error(void) { return g_err; }
 int t2_version(void) { return 1; }
+int t2_set_precision(int mode) {
+    T2_REQUIRE(mode == 0 || mode == 1, "t2_set_precision: mode must be 0 (fp32) or 1 (bf16 operands)");
+    set_precision(mode);
+    return 0;
+}
+int t2_get_precision(void) { return get_precision(); }
 
 int t2_decoder_layout_query(const t2_dims* dims, int B, int T, int Tin, int Tsub, t2_decoder_layout* out) {
     T2_REQUIRE(dims && out, "null argument");

@@ -12,6 +12,10 @@
 
 namespace t2 {
 
+static int g_precision = 0;       // 0: fp32 operands (parity path), 1: bf16 operands for large GEMMs
+void set_precision(int p) { g_precision = p; }
+int get_precision() { return g_precision; }
+
 namespace {
 
 constexpr int BK = 16;
@@ -216,6 +220,176 @@ __global__ void splitk_reduce_kernel(GemmDesc d) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// bf16-operand variant (fp32 in HBM, converted while staging; fp32 accumulate):
+// v_mfma_f32_32x32x16_bf16, tile 128x128x64, LDS tiles row-major [row][k] bf16 at a 144-byte
+// pitch (odd number of 16-byte slots: ds_read_b128 fragment reads are conflict-free), double
+// buffered, next chunk prefetched into registers.  16x the matrix rate of the fp32 path, so
+// this kernel is bound by operand delivery (each thread moves 64 B of fp32 per MFMA).
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BK16 = 64, PK16 = BK16 + 8;
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4& lo, const f32x4& hi) {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = (__bf16)lo[j]; v[4 + j] = (__bf16)hi[j]; }
+    return v;
+}
+
+// 128 rows x 64 k, k contiguous in the source: 4 tasks (row, 8 k) per thread.
+__device__ __forceinline__ void load16_kc(const float* __restrict__ base, long srow, int row0, int nrows, int k0, int kend, int vec,
+                                          ConvAddr cv, bf16x8 (&regs)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = threadIdx.x + i * 256, row = row0 + (q >> 3), k = k0 + (q & 7) * 8;
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+        if (row < nrows && k < kend) {
+            if (cv.T) {                                      // C % 8 == 0: the 8 k's share one tap
+                const int dk = k / cv.C, ci = k - dk * cv.C, t = row % cv.T + dk - cv.pad;
+                if (t >= 0 && t < cv.T) {
+                    const float* p = base + (long)(row + dk - cv.pad) * cv.C + ci;
+                    lo = *reinterpret_cast<const f32x4*>(p); hi = *reinterpret_cast<const f32x4*>(p + 4);
+                }
+            } else {
+                const float* p = base + (long)row * srow + k;
+                if (vec && k + 7 < kend) {
+                    lo = *reinterpret_cast<const f32x4*>(p); hi = *reinterpret_cast<const f32x4*>(p + 4);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { if (k + j < kend) lo[j] = p[j]; if (k + 4 + j < kend) hi[j] = p[4 + j]; }
+                }
+            }
+        }
+        regs[i] = pack8(lo, hi);
+    }
+}
+__device__ __forceinline__ void store16_kc(__bf16* __restrict__ lds, const bf16x8 (&regs)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = threadIdx.x + i * 256;
+        *reinterpret_cast<bf16x8*>(lds + (q >> 3) * PK16 + (q & 7) * 8) = regs[i];
+    }
+}
+// 64 k-rows x 128 "rows" (m or n), rows contiguous in the source: one task (4 rows, 8 k) per thread.
+__device__ __forceinline__ void load16_mc(const float* __restrict__ base, long sk, int row0, int nrows, int k0, int kend, int vec,
+                                          ConvAddr cv, bf16x8 (&regs)[4]) {
+    const int row = row0 + (threadIdx.x & 31) * 4, kb = k0 + (threadIdx.x >> 5) * 8;
+    f32x4 v[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        const int k = kb + kk;
+        v[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (k < kend && row < nrows) {
+            if (cv.T) {
+                const int dk = row / cv.C, ci = row - dk * cv.C, t = k % cv.T + dk - cv.pad;
+                if (t >= 0 && t < cv.T) v[kk] = *reinterpret_cast<const f32x4*>(base + (long)(k + dk - cv.pad) * cv.C + ci);
+            } else {
+                const float* p = base + (long)k * sk + row;
+                if (vec && row + 3 < nrows) v[kk] = *reinterpret_cast<const f32x4*>(p);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (row + j < nrows) v[kk][j] = p[j];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm) {
+        bf16x8 o;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) o[kk] = (__bf16)v[kk][mm];
+        regs[mm] = o;
+    }
+}
+__device__ __forceinline__ void store16_mc(__bf16* __restrict__ lds, const bf16x8 (&regs)[4]) {
+    const int row = (threadIdx.x & 31) * 4, kb = (threadIdx.x >> 5) * 8;
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm) *reinterpret_cast<bf16x8*>(lds + (row + mm) * PK16 + kb) = regs[mm];
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmK g) {
+    const GemmDesc& d = g.d;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    __bf16* const lds = reinterpret_cast<__bf16*>(smem16);
+    auto As = [&](int b) { return lds + b * (128 * PK16); };
+    auto Bs = [&](int b) { return lds + (2 + b) * (128 * PK16); };
+
+    const int z = blockIdx.z;
+    const int split = z % d.splitk, bz = z / d.splitk;
+    const float* A = d.A + (long)bz * d.bsA;
+    const float* B = d.B + (long)bz * d.bsB;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int kbeg = split * g.kchunks * BK, kend = min(d.K, kbeg + g.kchunks * BK);   // kchunks counts 16-wide chunks
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const ConvAddr cva{d.conv_a ? d.conv_T : 0, d.conv_C, d.conv_pad}, cvb{d.conv_b ? d.conv_T : 0, d.conv_C, d.conv_pad};
+    bf16x8 ra[4], rb[4];
+    auto load = [&](int k0) {
+        if (A_KC) load16_kc(A, d.sam, m0, d.M, k0, kend, g.avec, cva, ra); else load16_mc(A, d.sak, m0, d.M, k0, kend, g.avec, cva, ra);
+        if (B_KC) load16_kc(B, d.sbn, n0, d.N, k0, kend, g.bvec, cvb, rb); else load16_mc(B, d.sbk, n0, d.N, k0, kend, g.bvec, cvb, rb);
+    };
+    auto store = [&](int b) {
+        if (A_KC) store16_kc(As(b), ra); else store16_mc(As(b), ra);
+        if (B_KC) store16_kc(Bs(b), rb); else store16_mc(Bs(b), rb);
+    };
+    if (kbeg < kend) { load(kbeg); store(0); }
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK16) {
+        const bool more = k0 + BK16 < kend;
+        if (more) load(k0 + BK16);
+        const __bf16* as = As(cur) + (wm * 64 + r) * PK16 + 8 * h;
+        const __bf16* bs = Bs(cur) + (wn * 64 + r) * PK16 + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < BK16 / 16; ++ks) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * PK16 + ks * 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * PK16 + ks * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    const RngKey key = rng_key(d.seed, d.site);
+    float* C = d.C + (long)bz * d.bsC;
+    float* ws = d.splitk > 1 ? d.ws + ((long)split * d.batch + bz) * (long)d.M * d.N : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + r;
+            if (n >= d.N) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m >= d.M) continue;
+                if (ws) ws[(long)m * d.N + n] = acc[i][j][e];
+                else epilogue_store(d, C, m, n, acc[i][j][e], key);
+            }
+        }
+}
+
 template <int BM, int BN>
 void launch_cfg(const GemmK& g, bool akc, bool bkc, dim3 grid, hipStream_t s) {
     if (akc && bkc) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true>), grid, dim3(256), 0, s, g);
@@ -247,11 +421,17 @@ int gemm(const GemmDesc& din, hipStream_t s) {
     g.avec = aligned16(d.A) && (d.bsA % 4 == 0) && ((akc ? d.sam : d.sak) % 4 == 0);
     g.bvec = aligned16(d.B) && (d.bsB % 4 == 0) && ((bkc ? d.sbn : d.sbk) % 4 == 0);
 
-    const bool small = (d.M <= 64 || d.N <= 64) ||
-                       ((long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch < 256);
+    // 128x128 tiles whenever both extents allow it (4 MFMAs per 4 LDS fragment reads); a grid that
+    // would not fill the chip is completed by split-K when scratch is available, else by 64x64 tiles.
+    // bf16-operand mode: large GEMMs only (both extents >= 64), conv operands need C % 8 == 0
+    const bool use_bf16 = g_precision == 1 && !d.fp32_only && d.M >= 64 && d.N >= 64 && d.K >= 64 &&
+                          (!(d.conv_a || d.conv_b) || d.conv_C % 8 == 0);
+    const int kch = (d.K + BK - 1) / BK;
+    const bool can_split = d.ws && d.beta == 0.f && kch >= 64;
+    const long tiles128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch;
+    const bool small = !use_bf16 && ((d.M <= 64 || d.N <= 64) || (tiles128 < 256 && !can_split));
     const int BMN = small ? 64 : 128;
     const int tm = (d.M + BMN - 1) / BMN, tn = (d.N + BMN - 1) / BMN;
-    const int kch = (d.K + BK - 1) / BK;
     int splitk = 1;
     if (d.ws && d.beta == 0.f) {
         splitk = d.splitk;
@@ -268,11 +448,26 @@ int gemm(const GemmDesc& din, hipStream_t s) {
         if (splitk < 1) splitk = 1;
     }
     g.kchunks = (kch + splitk - 1) / splitk;
+    if (use_bf16) g.kchunks = (g.kchunks + 3) & ~3;   // whole 64-wide chunks per split
     splitk = (kch + g.kchunks - 1) / g.kchunks;     // drop empty splits
     d.splitk = splitk;
     T2_REQUIRE((long)d.batch * splitk <= 65535, "gemm: batch*splitk too large (%d*%d)", d.batch, splitk);
     dim3 grid(tn, tm, d.batch * splitk);
-    if (small) launch_cfg<64, 64>(g, akc, bkc, grid, s);
+    if (use_bf16) {
+        const size_t smem = (size_t)4 * 128 * PK16 * sizeof(__bf16);
+        static bool attr_set = false;
+        if (!attr_set) {
+            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr_set = true;
+        }
+        if (akc && bkc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), smem, s, g);
+        else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, dim3(256), smem, s, g);
+        else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(256), smem, s, g);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(256), smem, s, g);
+    } else if (small) launch_cfg<64, 64>(g, akc, bkc, grid, s);
     else launch_cfg<128, 128>(g, akc, bkc, grid, s);
     T2_LAUNCH_CHECK();
     if (splitk > 1) {

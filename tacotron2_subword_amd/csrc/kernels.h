@@ -25,6 +25,7 @@ struct GemmDesc {
     int splitk;                                   // 0 = choose automatically
     int conv_a, conv_b, conv_T, conv_C, conv_pad; // implicit im2col operand (gemm.hip ConvAddr): A rows / B k-rows are
                                                   // frames of X[B*T, C], the other index is dk*C + ci
+    int fp32_only;                                // never use the bf16-operand kernel for this product
     int crow_mod; long crow_mul;                  // output row = (m % crow_mod) * crow_mul + m / crow_mod (0 = identity):
                                                   // writes time-major rows (t,b) in batch-major order (b,t) or back
 };
@@ -32,6 +33,8 @@ inline GemmDesc gemm_desc() {
     GemmDesc d{}; d.batch = 1; d.alpha = 1.f; d.beta = 0.f; d.act = ACT_NONE; d.drop_p = 0.f; return d;
 }
 int gemm(const GemmDesc& d, hipStream_t s);
+void set_precision(int p);   // 0 fp32 operands, 1 bf16 operands (fp32 accumulate) for large GEMMs and LSTM steps
+int get_precision();
 
 // ------------------------------------------------------------------ LSTM (lstm.hip)
 constexpr int kMaxSeg = 6;

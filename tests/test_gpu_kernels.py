@@ -82,3 +82,25 @@ def test_rng_statistics_and_determinism(ops):
     assert torch.isfinite(z).all()
     zc = z.cpu()
     assert abs(float((zc[:-1] * zc[1:]).mean())) < 5e-3       # neighbouring indices decorrelated
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 512, 1024), (200, 130, 328), (2560, 512, 400), (4096, 256, 6400)])
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, True), (True, False)])
+def test_gemm_bf16_operands(ops, M, N, K, ta, tb):
+    """bf16-operand mode: same layouts, fp32 accumulate; error bounded by bf16 rounding of the operands."""
+    from tacotron2_subword_amd import _lib as L
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g).cuda()
+    B = torch.randn((N, K) if tb else (K, N), generator=g).cuda()
+    ws = torch.empty(16 * M * N, device="cuda")
+    L.set_precision("bf16")
+    try:
+        C = ops.gemm(A, B, trans_a=ta, trans_b=tb)
+        C2 = ops.gemm(A, B, trans_a=ta, trans_b=tb, ws=ws, splitk=4)
+    finally:
+        L.set_precision("f32")
+    # reference on bf16-rounded operands (exact products, fp64 accumulate)
+    ref = _ref(A.bfloat16().float(), B.bfloat16().float(), ta, tb)
+    assert (C.double().cpu() - ref).abs().max().item() < 2e-3 * max(1.0, K ** 0.5 / 8)
+    assert (C2.double().cpu() - ref).abs().max().item() < 2e-3 * max(1.0, K ** 0.5 / 8)
+    assert L.get_precision() == "f32"

@@ -172,3 +172,22 @@ def test_training_mode_full_model_vs_oracle():
     sd = m.state_dict()
     for k, v in stats.items():
         assert maxabs(sd[k].float(), v.float()) < 1e-5, k
+
+
+def test_bf16_operand_mode_stays_close_to_fp32_golden():
+    """bf16-operand GEMMs (fp32 accumulate and state) are the throughput mode, not the parity mode: this
+    records how far the outputs move on the BASELINE-shaped golden case (400 recurrent frames)."""
+    from tacotron2_subword_amd import _lib as L
+    g = load_golden("sma_baseline_eval")
+    B, Tin, Tsub, T, _ = (int(v) for v in g["meta"])
+    m, hps = build_model(SMA)
+    x, y = m.parse_batch(recipe.make_batch(hp_for(SMA), B, Tin, Tsub, T))
+    L.set_precision("bf16")
+    try:
+        with torch.no_grad():
+            out = m(x)
+    finally:
+        L.set_precision("f32")
+    errs = {k: maxabs(v, g[k]) for k, v in zip(("mel", "mel_postnet", "gate", "align"), out)}
+    print("bf16-operand max-abs error vs reference fp32:", errs)
+    assert errs["mel"] < 0.1 and errs["mel_postnet"] < 0.15 and errs["align"] < 0.1
