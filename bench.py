@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--tsub", type=int, default=60)
     ap.add_argument("--frames", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16",
                     help="GEMM operand type: f32 = exact fp32 (parity path); bf16 = bf16 operands, fp32 accumulate/state")
     a = ap.parse_args()
 
@@ -147,7 +147,8 @@ def main():
     roof, kernels = None, None
     if rank == 0:
         L.prof_enable(8 * Tn + 64)
-        T.train_step(model, criterion, optimizer, x, y, hp, it)
+    T.train_step(model, criterion, optimizer, x, y, hp, it)      # every rank takes the step (it contains collectives)
+    if rank == 0:
         prof = L.prof_collect()
         torch.cuda.synchronize()
         fl, by = decoder_step_flops(hp, B, Tin, Tsub), decoder_step_bytes(hp, B, Tin, Tsub)
@@ -192,7 +193,10 @@ def main():
                    "global_batch": world * B, "frames_per_item": Tn, "parallelism": f"dp{world}",
                    "hip_kernels": "embeddings, encoder conv/BN + BiLSTM, converters, decoder (prenets, attention LSTMs, SMA, "
                                   "decoder LSTM, projections), postnet conv/BN: forward and backward",
-                   "torch_ops": "loss reductions, clip_grad_norm_, Adam, cat/transpose copies"},
+                   "torch_ops": "loss reductions, clip_grad_norm_, Adam, cat/transpose copies",
+                   "precision": ("bf16 operands / fp32 accumulate for the large GEMMs (hoisted LSTM input halves, convolutions, "
+                                 "projections, weight gradients); per-step recurrent GEMMs, LSTM state, BatchNorm statistics and "
+                                 "attention recurrences fp32") if a.dtype == "bf16" else "fp32 everywhere (the parity path)"},
         "loss": round(loss_val, 5),
         "roofline": roof, "kernels": kernels,
     }

@@ -239,8 +239,12 @@ __global__ __launch_bounds__(NTB) void attention_step_bwd_kernel(AttnBwdDesc d) 
         for (int i = 0; i < 3; ++i) if (st.dctx[i]) v += st.dctx[i][(long)b * st.lddctx[i] + c];
         if (st.part && !d.first) {
             const float* p = st.part + (long)b * st.ldpart + st.part_col + c;
+            float pv[8];                              // all K-split partials requested at once (nparts <= 8)
+#pragma unroll
+            for (int z = 0; z < 8; ++z) pv[z] = z < st.nparts ? p[(long)z * st.part_stride] : 0.f;
             float acc = 0.f;
-            for (int z = 0; z < st.nparts; ++z) acc += p[(long)z * st.part_stride];
+#pragma unroll
+            for (int z = 0; z < 8; ++z) acc += pv[z];
             v += acc;
         }
         dctx[c] = v;
@@ -251,22 +255,34 @@ __global__ __launch_bounds__(NTB) void attention_step_bwd_kernel(AttnBwdDesc d) 
     if (tid == 0) g[Tin] = 0.f;
     __syncthreads();
 
-    // g_j: one wave per position, lanes stride the E channels 16 B at a time
+    // g_j: one wave per position, lanes stride the E channels 16 B at a time; 4 positions are in
+    // flight per wave so that the row loads overlap instead of serialising on L2 latency
     {
         const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll 2
-        for (int j = wave; j < Tin; j += NTB / 64) {
-            const float* mr = st.memory + ((long)b * Tin + j) * E;
-            float sum = 0.f;
+        constexpr int NWV = NTB / 64, U = 4;
+        for (int j0 = wave; j0 < Tin; j0 += NWV * U) {
+            float sum[U] = {0.f, 0.f, 0.f, 0.f};
             for (int c = lane * 4; c < E; c += 256) {
-                const f32x4 mv = *reinterpret_cast<const f32x4*>(mr + c);
-                sum += mv[0] * dctx[c] + mv[1] * dctx[c + 1] + mv[2] * dctx[c + 2] + mv[3] * dctx[c + 3];
+                const f32x4 dc = *reinterpret_cast<const f32x4*>(dctx + c);
+                f32x4 mv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {           // clamp instead of branching: the U loads issue back to back
+                    const int j = min(j0 + u * NWV, Tin - 1);
+                    mv[u] = *reinterpret_cast<const f32x4*>(st.memory + ((long)b * Tin + j) * E + c);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) sum[u] += mv[u][0] * dc[0] + mv[u][1] * dc[1] + mv[u][2] * dc[2] + mv[u][3] * dc[3];
             }
-            sum = wave_sum(sum);
-            if (lane == 0) {
-                if (st.dalign) sum += st.dalign[(long)b * st.lddalign + j];
-                if (!d.first) sum += st.carry[(long)b * Tin + j];
-                g[j] = sum;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u * NWV;
+                const float tot = wave_sum(sum[u]);
+                if (lane == 0 && j < Tin) {
+                    float gsum = tot;
+                    if (st.dalign) gsum += st.dalign[(long)b * st.lddalign + j];
+                    if (!d.first) gsum += st.carry[(long)b * Tin + j];
+                    g[j] = gsum;
+                }
             }
         }
     }

@@ -295,8 +295,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(LstmBwdPointDes
     if (st.dh2) dh += st.dh2[(long)b * st.lddh2 + u];
     if (st.part && !d.first) {
         const float* p = st.part + (long)b * st.ldpart + st.part_col + u;
+        float pv[8];                                  // all K-split partials requested at once (nparts <= 8)
+#pragma unroll
+        for (int z = 0; z < 8; ++z) pv[z] = z < st.nparts ? p[(long)z * st.part_stride] : 0.f;
         float acc = 0.f;
-        for (int z = 0; z < st.nparts; ++z) acc += p[(long)z * st.part_stride];
+#pragma unroll
+        for (int z = 0; z < 8; ++z) acc += pv[z];
         dh += acc;
     }
     if (st.dq) {
