@@ -57,6 +57,16 @@ template <int R, bool KC>
 __device__ __forceinline__ void load_tile(const float* __restrict__ base, long srow, long sk, int row0, int nrows,
                                           int k0, int kend, int vec, ConvAddr cv, f32x4 (&regs)[R * 4 / 256]) {
     constexpr int NQ = R * 4 / 256;
+    if (!cv.T && vec && row0 + R <= nrows && k0 + BK <= kend) {          // interior tile: unconditional 16-byte loads
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = threadIdx.x + i * 256;
+            const float* p = KC ? base + (long)(row0 + (q >> 2)) * srow + k0 + (q & 3) * 4
+                                : base + (long)(k0 + q / (R / 4)) * sk + row0 + (q % (R / 4)) * 4;
+            regs[i] = *reinterpret_cast<const f32x4*>(p);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         int q = threadIdx.x + i * 256;
@@ -223,13 +233,16 @@ __global__ void splitk_reduce_kernel(GemmDesc d) {
 
 // ---------------------------------------------------------------------------------------------
 // bf16-operand variant (fp32 in HBM, converted while staging; fp32 accumulate):
-// v_mfma_f32_32x32x16_bf16, tile 128x128x64, LDS tiles row-major [row][k] bf16 at a 144-byte
-// pitch (odd number of 16-byte slots: ds_read_b128 fragment reads are conflict-free), double
-// buffered, next chunk prefetched into registers.  16x the matrix rate of the fp32 path, so
+// v_mfma_f32_32x32x16_bf16, tile 128x128x64, LDS tiles row-major [row][k] bf16 with an XOR
+// swizzle of the 16-byte slots (swz16), double buffered, next chunk prefetched into registers.  16x the matrix rate of the fp32 path, so
 // this kernel is bound by operand delivery (each thread moves 64 B of fp32 per MFMA).
 // ---------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int BK16 = 64, PK16 = BK16 + 8;
+constexpr int BK16 = 64, PK16 = BK16;
+// 16-byte slot s (8 bf16) of row R lives at slot s ^ ((R ^ (R >> 2)) & 7): with unpadded 128-byte rows this
+// makes the K-contiguous stores, the row-contiguous (transposing) stores and the ds_read_b128 fragment
+// reads all bank-conflict-free (checked exhaustively over the lane groups of MI355X_MICROARCH.md §LDS).
+__device__ __forceinline__ int swz16(int row, int slot) { return row * PK16 + ((slot ^ ((row ^ (row >> 2)) & 7)) << 3); }
 
 __device__ __forceinline__ bf16x8 pack8(const f32x4& lo, const f32x4& hi) {
     bf16x8 v;
@@ -241,6 +254,36 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& lo, const f32x4& hi) {
 // 128 rows x 64 k, k contiguous in the source: 4 tasks (row, 8 k) per thread.
 __device__ __forceinline__ void load16_kc(const float* __restrict__ base, long srow, int row0, int nrows, int k0, int kend, int vec,
                                           ConvAddr cv, bf16x8 (&regs)[4]) {
+    if (cv.T && row0 + 128 <= nrows && k0 + BK16 <= kend) {              // implicit-conv interior tile: select, no branches
+        f32x4 lo[4], hi[4];
+        bool ok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = threadIdx.x + i * 256, row = row0 + (q >> 3), k = k0 + (q & 7) * 8;
+            const int dk = k / cv.C, ci = k - dk * cv.C, t = row % cv.T + dk - cv.pad;
+            ok[i] = t >= 0 && t < cv.T;
+            const float* p = base + (ok[i] ? (long)(row + dk - cv.pad) * cv.C + ci : 0l);
+            lo[i] = *reinterpret_cast<const f32x4*>(p); hi[i] = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
+            regs[i] = pack8(ok[i] ? lo[i] : zz, ok[i] ? hi[i] : zz);
+        }
+        return;
+    }
+    if (!cv.T && vec && row0 + 128 <= nrows && k0 + BK16 <= kend) {     // interior tile: unconditional 16-byte loads
+        f32x4 lo[4], hi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = threadIdx.x + i * 256;
+            const float* p = base + (long)(row0 + (q >> 3)) * srow + k0 + (q & 7) * 8;
+            lo[i] = *reinterpret_cast<const f32x4*>(p); hi[i] = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) regs[i] = pack8(lo[i], hi[i]);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int q = threadIdx.x + i * 256, row = row0 + (q >> 3), k = k0 + (q & 7) * 8;
@@ -269,7 +312,7 @@ __device__ __forceinline__ void store16_kc(__bf16* __restrict__ lds, const bf16x
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int q = threadIdx.x + i * 256;
-        *reinterpret_cast<bf16x8*>(lds + (q >> 3) * PK16 + (q & 7) * 8) = regs[i];
+        *reinterpret_cast<bf16x8*>(lds + swz16(q >> 3, q & 7)) = regs[i];
     }
 }
 // 64 k-rows x 128 "rows" (m or n), rows contiguous in the source: one task (4 rows, 8 k) per thread.
@@ -277,6 +320,20 @@ __device__ __forceinline__ void load16_mc(const float* __restrict__ base, long s
                                           ConvAddr cv, bf16x8 (&regs)[4]) {
     const int row = row0 + (threadIdx.x & 31) * 4, kb = k0 + (threadIdx.x >> 5) * 8;
     f32x4 v[8];
+    if (!cv.T && vec && row0 + 128 <= nrows && k0 + BK16 <= kend) {     // interior tile: 8 unconditional 16-byte loads
+        const float* p = base + (long)kb * sk + row;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) v[kk] = *reinterpret_cast<const f32x4*>(p + (long)kk * sk);
+    } else if (cv.T && row0 + 128 <= nrows && k0 + BK16 <= kend) {       // implicit-conv interior tile: select, no branches
+        const int dk = row / cv.C, ci = row - dk * cv.C;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int k = kb + kk, t = k % cv.T + dk - cv.pad;
+            const bool ok = t >= 0 && t < cv.T;
+            const f32x4 x = *reinterpret_cast<const f32x4*>(base + (ok ? (long)(k + dk - cv.pad) * cv.C + ci : 0l));
+            v[kk] = ok ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    } else
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
         const int k = kb + kk;
@@ -304,9 +361,9 @@ __device__ __forceinline__ void load16_mc(const float* __restrict__ base, long s
     }
 }
 __device__ __forceinline__ void store16_mc(__bf16* __restrict__ lds, const bf16x8 (&regs)[4]) {
-    const int row = (threadIdx.x & 31) * 4, kb = (threadIdx.x >> 5) * 8;
+    const int row = (threadIdx.x & 31) * 4, ks = threadIdx.x >> 5;
 #pragma unroll
-    for (int mm = 0; mm < 4; ++mm) *reinterpret_cast<bf16x8*>(lds + (row + mm) * PK16 + kb) = regs[mm];
+    for (int mm = 0; mm < 4; ++mm) *reinterpret_cast<bf16x8*>(lds + swz16(row + mm, ks)) = regs[mm];
 }
 
 template <bool A_KC, bool B_KC>
@@ -352,15 +409,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmK g) {
     for (int k0 = kbeg; k0 < kend; k0 += BK16) {
         const bool more = k0 + BK16 < kend;
         if (more) load(k0 + BK16);
-        const __bf16* as = As(cur) + (wm * 64 + r) * PK16 + 8 * h;
-        const __bf16* bs = Bs(cur) + (wn * 64 + r) * PK16 + 8 * h;
+        const __bf16* as = As(cur);
+        const __bf16* bs = Bs(cur);
 #pragma unroll
         for (int ks = 0; ks < BK16 / 16; ++ks) {
             bf16x8 a[2], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * PK16 + ks * 16);
+            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(as + swz16(wm * 64 + i * 32 + r, 2 * ks + h));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * PK16 + ks * 16);
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bs + swz16(wn * 64 + j * 32 + r, 2 * ks + h));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll

@@ -67,9 +67,13 @@ template <int R, int BKT, int Q, typename RowPtr>
 __device__ __forceinline__ void load_rows(RowPtr rowptr, int k0, f32x4 (&regs)[Q]) {
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
+        // branch-free: rowptr clamps out-of-range rows to a valid one and reports validity; a per-lane
+        // branch around each load would stop the compiler from issuing the stage's loads back to back
         const int q = threadIdx.x + i * NTH, row = q / (BKT / 4), k = (q % (BKT / 4)) * 4;
-        const float* p = rowptr(row);
-        regs[i] = p ? *reinterpret_cast<const f32x4*>(p + k0 + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bool ok;
+        const float* p = rowptr(row, ok);
+        const f32x4 x = *reinterpret_cast<const f32x4*>(p + k0 + k);
+        regs[i] = ok ? x : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 template <int BKT, int Q>
@@ -152,9 +156,9 @@ __global__ __launch_bounds__(NTH) void lstm_step_fwd_kernel(LstmStepDesc d) {
     int seg = 0, kin = 0;                            // position of the NEXT stage to load
     auto load_next = [&]() {
         const LstmSeg sg = st.seg[seg];
-        load_rows<MT * 32, BKT, TL::QA>([&](int row) { return row < B ? sg.x + (long)row * sg.ldx : nullptr; }, kin, ra);
+        load_rows<MT * 32, BKT, TL::QA>([&](int row, bool& ok) { ok = row < B; return sg.x + (long)(ok ? row : 0) * sg.ldx; }, kin, ra);
         // column n = gate*8 + unit  ->  row (n/8)*H + u0 + n%8 of W
-        load_rows<32, BKT, TL::QB>([&](int n) { return sg.w + (long)((n >> 3) * H + u0 + (n & 7)) * sg.ldw; }, kin, rb);
+        load_rows<32, BKT, TL::QB>([&](int n, bool& ok) { ok = true; return sg.w + (long)((n >> 3) * H + u0 + (n & 7)) * sg.ldw; }, kin, rb);
         kin += BKT;
         if (kin >= sg.k) { kin = 0; ++seg; }
     };
@@ -169,18 +173,16 @@ __global__ __launch_bounds__(NTH) void lstm_step_fwd_kernel(LstmStepDesc d) {
         const int bl = threadIdx.x >> 3, u = u0 + (threadIdx.x & 7);
 #pragma unroll
         for (int m = 0; m < (kPrefetch ? MT : 1); ++m) {
-            const int b = m * 32 + bl;
+            const int b = min(m * 32 + bl, B - 1);            // clamped: rows >= B are never consumed
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float v = 0.f;
-                if (b < B) {
-                    if (st.pre) v += st.pre[(long)b * st.ldpre + g * H + u];
-                    if (st.bias1) v += st.bias1[g * H + u];
-                    if (st.bias2) v += st.bias2[g * H + u];
-                }
+                if (st.pre) v += st.pre[(long)b * st.ldpre + g * H + u];          // wave-uniform conditions
+                if (st.bias1) v += st.bias1[g * H + u];
+                if (st.bias2) v += st.bias2[g * H + u];
                 pre_v[m][g] = v;
             }
-            cp_v[m] = (b < B && st.c_prev) ? st.c_prev[(long)b * st.ldc_prev + u] : 0.f;
+            cp_v[m] = st.c_prev ? st.c_prev[(long)b * st.ldc_prev + u] : 0.f;
         }
     }
 
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(NTH) void lstm_bwd_gemm_kernel(LstmBwdGemmDesc d) {
     const bool wvec = (sg.ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(sg.w) & 15) == 0);
     f32x4 ra[TL::QA], rb[TL::QB];
     auto load_stage = [&](int c) {
-        load_rows<MT * 32, BKT, TL::QA>([&](int row) { return row < B ? st.dg + (long)row * st.lddg + kbeg : nullptr; }, c * BKT, ra);
+        load_rows<MT * 32, BKT, TL::QA>([&](int row, bool& ok) { ok = row < B; return st.dg + (long)(ok ? row : 0) * st.lddg + kbeg; }, c * BKT, ra);
 #pragma unroll
         for (int i = 0; i < TL::QB; ++i) {
             const int q = threadIdx.x + i * NTH, k = q >> 3, n = (q & 7) * 4;
