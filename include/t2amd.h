@@ -95,6 +95,9 @@ typedef struct t2_decoder_layout {
     size_t dout;                      /* [T,B, Hd+2*E] = dec_h | ctx | ctx_sub */
     size_t qs, qss;                   /* processed query per step [T,B,A] */
     size_t qpart;                     /* per-step scratch [2][Ha/8][B][A] */
+    /* bf16-operand mode (sizes in floats = bf16 elements / 2): weight shadows [W_hh | W_ih[:,P:]] per stream,
+     * decoder W_hh, their transposes for the backward pass, and bf16 copies of DIN / dec_h */
+    size_t w16a, w16as, w16d, wt16a, wt16as, wt16d, din16, dh16;
     size_t gemm_ws; size_t gemm_ws_floats;
 } t2_decoder_layout;
 
@@ -136,7 +139,7 @@ typedef struct t2_decoder_grads {
 typedef struct t2_decoder_bwd_layout {
     size_t total_floats;
     size_t ddout, ddin, dgd, dga, dgas, dctx, dctxs, dq, dqs, dv, dvs, dpm, dpms, carry, carrys;
-    size_t dcd, dca, dcas, partd, parta, dp2, dp2s, dp1, dmel_t, dgate_t, colsum_ws, gemm_ws, gemm_ws_floats;
+    size_t dcd, dca, dcas, partd, parta, dp2, dp2s, dp1, dmel_t, dgate_t, dg16a, dg16d, colsum_ws, gemm_ws, gemm_ws_floats;
 } t2_decoder_bwd_layout;
 int t2_decoder_bwd_layout_query(const t2_dims* dims, int B, int T, int Tin, int Tsub, t2_decoder_bwd_layout* out);
 typedef struct t2_decoder_bwd_args {

@@ -46,7 +46,8 @@ class DecoderWeights(C.Structure):
 
 _LAYOUT_FIELDS = ["total_floats", "x", "p1", "p2", "p1s", "p2s", "pm", "pms", "prea", "preas", "ga", "gas",
                   "cna", "cnas", "ca", "cas", "din", "psel", "psels", "wcum", "wcums", "pred", "gd", "cnd", "cd",
-                  "dout", "qs", "qss", "qpart", "gemm_ws", "gemm_ws_floats"]
+                  "dout", "qs", "qss", "qpart", "w16a", "w16as", "w16d", "wt16a", "wt16as", "wt16d", "din16", "dh16",
+                  "gemm_ws", "gemm_ws_floats"]
 
 
 class DecoderLayout(C.Structure):
@@ -86,7 +87,7 @@ class DecoderGrads(C.Structure):
 
 _BWD_LAYOUT_FIELDS = ["total_floats", "ddout", "ddin", "dgd", "dga", "dgas", "dctx", "dctxs", "dq", "dqs", "dv", "dvs",
                       "dpm", "dpms", "carry", "carrys", "dcd", "dca", "dcas", "partd", "parta", "dp2", "dp2s", "dp1",
-                      "dmel_t", "dgate_t", "colsum_ws", "gemm_ws", "gemm_ws_floats"]
+                      "dmel_t", "dgate_t", "dg16a", "dg16d", "colsum_ws", "gemm_ws", "gemm_ws_floats"]
 
 
 class DecoderBwdLayout(C.Structure):

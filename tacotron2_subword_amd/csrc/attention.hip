@@ -203,6 +203,7 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
             for (int h2 = 0; h2 < nh; ++h2) sum += cred[h2 * E + c];
             st.ctx1[(long)b * st.ldctx1 + c] = sum;
             if (st.ctx2) st.ctx2[(long)b * st.ldctx2 + c] = sum;
+            if (st.ctx16) st.ctx16[(long)b * st.ldctx16 + c] = (__bf16)sum;
         }
     }
 }

@@ -94,6 +94,10 @@ void layout_of(const t2_dims& d, const Sizes& z, t2_decoder_layout* L) {
     L->dout = take(BT * z.WO);
     L->qs = take(BT * z.A); L->qss = take(BT * z.A);
     L->qpart = take((size_t)2 * (z.Ha / 8) * z.B * z.A);
+    const size_t na = (size_t)4 * z.Ha * (z.Ha + z.E) / 2, nd = (size_t)4 * z.Hd * z.Hd / 2;      // bf16 pairs per float
+    L->w16a = take(na); L->w16as = take(na); L->w16d = take(nd);
+    L->wt16a = take(na); L->wt16as = take(na); L->wt16d = take(nd);
+    L->din16 = take(BT * z.WD / 2 + 4); L->dh16 = take(BT * z.Hd / 2 + 4);
     L->gemm_ws_floats = (size_t)16 << 20;                     // 64 MiB of split-K scratch
     L->gemm_ws = take(L->gemm_ws_floats);
     L->total_floats = off;
@@ -104,7 +108,9 @@ struct Dec {
     const float* memory; const float* memory_sub; const int32_t* len; const int32_t* len_sub;
     float* mel_out; float* gate_out; float* align; float* align_sub;
     bool training; bool prenet_dropout; bool teacher; uint64_t seed; hipStream_t s;
+    bool use16 = false;                              // bf16-operand recurrent steps (t2_set_precision(1), teacher-forced)
     float* P(size_t off) const { return ws + off; }
+    __bf16* P16(size_t off) const { return reinterpret_cast<__bf16*>(ws + off); }
     long R(int t) const { return (long)t * z.B; }      // first row of step t in a time-major [T,B,*] buffer
 };
 
@@ -133,6 +139,29 @@ int prenet(const Dec& c, bool sub, const float* X, long ldx, int M, float* P1, f
         h.drop_base = base; h.drop_mstride = mstride;
     }
     return gemm(h, c.s);
+}
+
+// bf16-operand recurrent steps: precision mode 1, B <= 64, recurrent widths multiples of 256
+bool use_bf16_steps(const t2_dims& d, const Sizes& z) {
+    return get_precision() == 1 && z.B <= 64 && (z.Ha + z.E) % 256 == 0 && z.Hd % 256 == 0 && (4 * z.Ha) % 2048 == 0 && (4 * z.Hd) % 2048 == 0;
+}
+// weight shadows for one pass: [W_hh | W_ih[:,P:]] (K-contiguous, forward) and its transpose laid out
+// [ctx columns | h columns] x 4H (backward), per attention stream; W_hh and W_hh^T of the decoder LSTM
+int cast_shadows(const t2_dims& d, const t2_decoder_weights& w, const Sizes& z, const t2_decoder_layout& L, float* ws, hipStream_t s) {
+    auto P16 = [&](size_t off) { return reinterpret_cast<__bf16*>(ws + off); };
+    const long K = z.Ha + z.E, ldi = z.P + z.E;
+    for (int st = 0; st < 2; ++st) {
+        const t2_lstm_weights& lw = st ? w.att_sub : w.att;
+        __bf16* f = P16(st ? L.w16as : L.w16a);
+        T2_TRY(cast_rows_bf16(lw.w_hh, z.Ha, f, K, 4 * z.Ha, z.Ha, s));
+        T2_TRY(cast_rows_bf16(lw.w_ih + z.P, ldi, f + z.Ha, K, 4 * z.Ha, z.E, s));
+        __bf16* tr = P16(st ? L.wt16as : L.wt16a);
+        T2_TRY(cast_transpose_bf16(lw.w_ih + z.P, ldi, tr, 4 * z.Ha, 4 * z.Ha, z.E, s));
+        T2_TRY(cast_transpose_bf16(lw.w_hh, z.Ha, tr + (long)z.E * 4 * z.Ha, 4 * z.Ha, 4 * z.Ha, z.Ha, s));
+    }
+    T2_TRY(cast_rows_bf16(w.dec.w_hh, z.Hd, P16(L.w16d), z.Hd, 4 * z.Hd, z.Hd, s));
+    T2_TRY(cast_transpose_bf16(w.dec.w_hh, z.Hd, P16(L.wt16d), 4 * z.Hd, 4 * z.Hd, z.Hd, s));
+    return 0;
 }
 
 int att_lstm_step(const Dec& c, int t) {
@@ -166,6 +195,13 @@ int att_lstm_step(const Dec& c, int t) {
         st.idx_base = (uint32_t)(c.R(t) * z.Ha); st.idx_bstride = (uint32_t)z.Ha;       // logical [T,B,Ha]
         st.wq = s ? c.w.attn_sub.wq : c.w.attn.wq; st.A = z.A;
         st.qpart = c.P(L.qpart) + (size_t)s * (z.Ha / 8) * z.B * z.A;
+        if (c.use16) {                               // one K-contiguous bf16 segment [h | ctx] x [W_hh | W_ih[:,P:]]
+            __bf16* D16 = c.P16(L.din16);
+            st.nseg = 0;
+            st.x16 = D16 + (t > 0 ? c.R(t - 1) * z.WD + hoff : 0); st.ldx16 = z.WD;
+            st.w16 = c.P16(s ? L.w16as : L.w16a); st.ldw16 = z.Ha + z.E; st.k16 = t > 0 ? z.Ha + z.E : 0;
+            st.h16_out = D16 + c.R(t) * z.WD + hoff; st.ldh16 = z.WD;
+        }
     }
     ProfScope ps(PK_LSTM_ATT_FWD, c.s);
     return lstm_step_fwd(d, c.s);
@@ -200,6 +236,7 @@ int attention_step(const Dec& c, int t) {
         }
         st.ctx1 = c.P(L.din) + c.R(t) * z.WD + (s ? 2 * z.Ha + z.E : z.Ha); st.ldctx1 = z.WD;
         st.ctx2 = c.P(L.dout) + c.R(t) * z.WO + z.Hd + (s ? z.E : 0); st.ldctx2 = z.WO;
+        if (c.use16) { st.ctx16 = c.P16(L.din16) + c.R(t) * z.WD + (s ? 2 * z.Ha + z.E : z.Ha); st.ldctx16 = z.WD; }
         st.v = aw.v; st.loc_conv = aw.loc_conv; st.loc_dense = aw.loc_dense;
         st.site_noise = s ? T2_SITE_NOISE_SUB : T2_SITE_NOISE;
         st.idx_base = (uint32_t)(c.R(t) * Tin); st.idx_bstride = (uint32_t)Tin;          // logical [T,B,Tin]
@@ -232,6 +269,13 @@ int dec_lstm_step(const Dec& c, int t) {
     st.h_out = c.P(L.dout) + c.R(t) * z.WO; st.ldh_out = z.WO;
     st.site_h = T2_SITE_DEC_H; st.site_c = T2_SITE_DEC_C;
     st.idx_base = (uint32_t)(c.R(t) * z.Hd); st.idx_bstride = (uint32_t)z.Hd;             // logical [T,B,Hd]
+    if (c.use16) {
+        __bf16* H16 = c.P16(L.dh16);
+        st.nseg = 0;
+        st.x16 = H16 + (t > 0 ? c.R(t - 1) * z.Hd : 0); st.ldx16 = z.Hd;
+        st.w16 = c.P16(L.w16d); st.ldw16 = z.Hd; st.k16 = t > 0 ? z.Hd : 0;
+        st.h16_out = H16 + c.R(t) * z.Hd; st.ldh16 = z.Hd;
+    }
     ProfScope ps(PK_LSTM_DEC_FWD, c.s);
     return lstm_step_fwd(d, c.s);
 }
@@ -289,6 +333,7 @@ void bwd_layout_of(const t2_dims& d, const Sizes& z, t2_decoder_bwd_layout* L) {
     L->parta = take((size_t)2 * ksa * z.B * (z.E + z.Ha));
     L->dp2 = take(BT * z.P); L->dp2s = take(BT * z.P); L->dp1 = take(BT * z.P);
     L->dmel_t = take(BT * z.M); L->dgate_t = take(BT);
+    L->dg16a = take((size_t)2 * z.B * 4 * z.Ha / 2 + 4); L->dg16d = take((size_t)z.B * 4 * z.Hd / 2 + 4);
     L->colsum_ws = take((size_t)64 * 4 * (z.Ha > z.Hd ? z.Ha : z.Hd));
     L->gemm_ws_floats = (size_t)48 << 20;                     // 192 MiB of split-K scratch
     L->gemm_ws = take(L->gemm_ws_floats);
@@ -301,6 +346,9 @@ struct Bwd {
     const float* W(size_t off) const { return a.ws + off; }
     float* S(size_t off) const { return a.bws + off; }
     long R(int t) const { return (long)t * z.B; }
+    bool use16 = false;
+    const __bf16* W16(size_t off) const { return reinterpret_cast<const __bf16*>(a.ws + off); }
+    __bf16* S16(size_t off) const { return reinterpret_cast<__bf16*>(a.bws + off); }
     float* gemm_ws() const { return a.bws + BL.gemm_ws; }
     size_t gemm_ws_bytes() const { return BL.gemm_ws_floats * sizeof(float); }
 };
@@ -339,6 +387,7 @@ int dec_bwd_step(const Bwd& c, int t) {
     st.dg = c.S(c.BL.dgd) + c.R(t) * 4 * z.Hd; st.lddg = 4 * z.Hd;
     st.site_h = T2_SITE_DEC_H; st.site_c = T2_SITE_DEC_C;
     st.idx_base = (uint32_t)(c.R(t) * z.Hd); st.idx_bstride = (uint32_t)z.Hd;
+    if (c.use16) st.dg16 = c.S16(c.BL.dg16d);
     { ProfScope ps(PK_LSTM_DEC_BWD_PW, c.s); T2_TRY(lstm_bwd_pointwise(p, c.s)); }
     if (t == 0) return 0;
     LstmBwdGemmDesc g{};
@@ -346,6 +395,7 @@ int dec_bwd_step(const Bwd& c, int t) {
     g.st[0].dg = st.dg; g.st[0].lddg = st.lddg;
     g.st[0].seg[0] = LstmBwdSeg{c.w.dec.w_hh, (long)z.Hd, z.Hd}; g.st[0].nseg = 1;
     g.st[0].part = c.S(c.BL.partd);
+    if (c.use16) { g.st[0].dg16 = c.S16(c.BL.dg16d); g.st[0].wt16 = c.W16(c.L.wt16d); }
     ProfScope ps(PK_LSTM_DEC_BWD_GEMM, c.s);
     return lstm_bwd_gemm(g, c.s);
 }
@@ -399,6 +449,7 @@ int att_bwd_step(const Bwd& c, int t) {
         st.dg = c.S(s ? c.BL.dgas : c.BL.dga) + c.R(t) * 4 * z.Ha; st.lddg = 4 * z.Ha;
         st.site_h = s ? T2_SITE_ATT_H_SUB : T2_SITE_ATT_H; st.site_c = s ? T2_SITE_ATT_C_SUB : T2_SITE_ATT_C;
         st.idx_base = (uint32_t)(c.R(t) * z.Ha); st.idx_bstride = (uint32_t)z.Ha;
+        if (c.use16) st.dg16 = c.S16(c.BL.dg16a) + (size_t)s * z.B * 4 * z.Ha;
     }
     { ProfScope ps(PK_LSTM_ATT_BWD_PW, c.s); T2_TRY(lstm_bwd_pointwise(p, c.s)); }
     if (t == 0) return 0;
@@ -412,6 +463,7 @@ int att_bwd_step(const Bwd& c, int t) {
         g.st[s].seg[1] = LstmBwdSeg{lw.w_hh, (long)z.Ha, z.Ha};
         g.st[s].nseg = 2;
         g.st[s].part = c.S(c.BL.parta) + (size_t)s * ks * z.B * NC;
+        if (c.use16) { g.st[s].dg16 = c.S16(c.BL.dg16a) + (size_t)s * z.B * 4 * z.Ha; g.st[s].wt16 = c.W16(s ? c.L.wt16as : c.L.wt16a); }
     }
     ProfScope ps(PK_LSTM_ATT_BWD_GEMM, c.s);
     return lstm_bwd_gemm(g, c.s);
@@ -451,6 +503,8 @@ int t2_decoder_forward(const t2_dims* dims, const t2_decoder_weights* w, const t
     const Sizes& z = c.z; const t2_decoder_layout& L = c.L;
     const int BT = z.B * z.T;
 
+    c.use16 = use_bf16_steps(*dims, z);
+    if (c.use16) T2_TRY(cast_shadows(*dims, *w, z, L, a->ws, c.s));
     // teacher inputs and both prenets over all frames (model.py:407-413)
     T2_TRY(teacher_inputs(a->mels, c.P(L.x), z.B, z.M, z.T, c.s));
     T2_TRY(prenet(c, false, c.P(L.x), z.M, BT, c.P(L.p1), c.P(L.p2), z.P, 0, 0));      // rows time-major: (t,b)
@@ -497,6 +551,7 @@ int t2_decoder_backward(const t2_dims* dims, const t2_decoder_weights* w, const 
     Bwd c{*dims, *w, *g, *a, sizes_of(*dims, a->B, a->T, a->Tin, a->Tsub), {}, {}, (hipStream_t)stream};
     layout_of(*dims, c.z, &c.L);
     bwd_layout_of(*dims, c.z, &c.BL);
+    c.use16 = use_bf16_steps(*dims, c.z);          // must match the forward pass (the shadows live in its workspace)
     const Sizes& z = c.z; const t2_decoder_layout& L = c.L; const t2_decoder_bwd_layout& BL = c.BL;
     const int BT = z.B * z.T;
     float* cws = c.S(BL.colsum_ws);

@@ -53,6 +53,9 @@ struct LstmStream {
     const int* lengths; int t;            // packed sequences: item active iff t < lengths[b] (nullable);
                                           // an inactive item writes zeros (state and output)
     const float* wq; int A; float* qpart; // optional fused query partials: qpart[H/8][B][A] (wq: [A,H])
+    // bf16-operand mode (one K-contiguous segment): x16 [B,k16] and w16 [4H,k16] shadows; h16_out = bf16 copy of h
+    const __bf16* x16; long ldx16; const __bf16* w16; long ldw16; int k16;
+    __bf16* h16_out; long ldh16;
 };
 constexpr int kMaxLstmStreams = 4;
 struct LstmStepDesc { LstmStream st[kMaxLstmStreams]; int nstreams; int B, H; float drop_p; uint64_t seed; };
@@ -70,6 +73,7 @@ struct LstmBwdStream {
     const float* c_prev; long ldc_prev;    // cell carried INTO step t (after dropout), null -> 0
     float* dc_state;                       // [B,H] running dL/dc_out, read (unless first) and replaced by dL/dc_prev
     float* dg; long lddg;                  // [B,4H] out: gradient wrt gate pre-activations
+    __bf16* dg16;                          // optional dense [B,4H] bf16 copy (bf16-operand recurrent GEMM)
     uint32_t site_h, site_c, idx_base, idx_bstride;
 };
 struct LstmBwdPointDesc { LstmBwdStream st[kMaxLstmStreams]; int nstreams; int B, H; float drop_p; uint64_t seed; int first; };
@@ -78,10 +82,16 @@ int lstm_bwd_pointwise(const LstmBwdPointDesc& d, hipStream_t s);
 // part 2 (skinny GEMM): partial products dL/dx_rec = dg(t) . W for the recurrent input columns,
 // split over column tiles x K-splits so that the whole chip works on one step.
 struct LstmBwdSeg { const float* w; long ldw; int ncols; };
-struct LstmBwdGemmStream { const float* dg; long lddg; LstmBwdSeg seg[3]; int nseg; float* part; };
+struct LstmBwdGemmStream {
+    const float* dg; long lddg; LstmBwdSeg seg[3]; int nseg; float* part;
+    const __bf16* dg16; const __bf16* wt16;   // bf16 variant: dense [B,4H] gradient copy, transposed weight shadow [NC,4H]
+};
 struct LstmBwdGemmDesc { LstmBwdGemmStream st[kMaxLstmStreams]; int nstreams; int B, H4, KS, NC; };
 int lstm_bwd_gemm(const LstmBwdGemmDesc& d, hipStream_t s);
 int lstm_bwd_ksplit(int H4);
+// bf16 shadows: dst[r*ld_dst + c] = bf16(src[r*ld_src + c]) ; transposed: dst[c*ld_dst + r]
+int cast_rows_bf16(const float* src, long ld_src, __bf16* dst, long ld_dst, int R, int C, hipStream_t s);
+int cast_transpose_bf16(const float* src, long ld_src, __bf16* dst, long ld_dst, int R, int C, hipStream_t s);
 
 // ------------------------------------------------------------------ attention (attention.hip)
 struct AttnStream {
@@ -98,6 +108,7 @@ struct AttnStream {
     float* wcum_out; long ldwcum_out;           // LSA cumulative weights after this step (nullable for SMA)
     float* ctx1; long ldctx1;             // [B,E]
     float* ctx2; long ldctx2;             // second destination (nullable)
+    __bf16* ctx16; long ldctx16;          // bf16 copy for the bf16-operand LSTM step (nullable)
     const float* v;                       // [A]
     const float* loc_conv; const float* loc_dense;   // LSA: [F,2,Kc], [A,F]
     uint32_t site_noise; uint32_t idx_base, idx_bstride;   // SMA noise index = idx_base + b*idx_bstride + j

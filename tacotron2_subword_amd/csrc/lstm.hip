@@ -127,6 +127,86 @@ __device__ __forceinline__ void compute_stage_bwd(const float* __restrict__ As, 
     }
 }
 
+// Everything after the K loop, shared by the fp32- and bf16-operand step kernels: sum the NW partial
+// tiles in fixed order, gates, cell update, dropout, stores, optional query-projection partials.
+template <int MT, bool kPrefetch>
+__device__ __forceinline__ void lstm_tail(const LstmStepDesc& d, const LstmStream& st, int u0, int wave, int r, int hk,
+                                          f32x16 (&acc)[MT], float* __restrict__ part, float* __restrict__ hs,
+                                          const float (&pre_v)[kPrefetch ? MT : 1][4], const float (&cp_v)[kPrefetch ? MT : 1]) {
+    const int B = d.B, H = d.H;
+    const RngKey kh = rng_key(d.seed, st.site_h), kc = rng_key(d.seed, st.site_c);
+    const float scale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (m > 0) __syncthreads();
+        // lane holds column r, rows (e&3) + 8*(e>>2) + 4*hk
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            part[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk) * PP + r] = acc[m][e];
+        __syncthreads();
+        if (threadIdx.x < 32 * HU) {
+            const int bl = threadIdx.x >> 3, uu = threadIdx.x & 7;
+            const int b = m * 32 + bl, u = u0 + uu;
+            if (b < B) {
+                float g4[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) sum += part[(w * 32 + bl) * PP + g * 8 + uu];
+                    if (kPrefetch) {
+                        sum += pre_v[kPrefetch ? m : 0][g];
+                    } else {
+                        if (st.pre) sum += st.pre[(long)b * st.ldpre + g * H + u];
+                        if (st.bias1) sum += st.bias1[g * H + u];
+                        if (st.bias2) sum += st.bias2[g * H + u];
+                    }
+                    g4[g] = sum;
+                }
+                const bool active = !st.lengths || st.t < st.lengths[b];
+                float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]), og = sigmoidf_(g4[3]);
+                const float cp = kPrefetch ? cp_v[kPrefetch ? m : 0] : (st.c_prev ? st.c_prev[(long)b * st.ldc_prev + u] : 0.f);
+                float cn = fg * cp + ig * gg;
+                float hn = og * tanhf(cn);
+                if (!active) { ig = fg = gg = og = 0.f; cn = 0.f; hn = 0.f; }
+                if (st.gates) {
+                    float* gp = st.gates + (long)b * st.ldgates + u;
+                    gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
+                }
+                if (st.c_new) st.c_new[(long)b * st.ldc_new + u] = cn;
+                float ho = hn, co = cn;
+                if (d.drop_p > 0.f) {
+                    const uint32_t idx = st.idx_base + (uint32_t)b * st.idx_bstride + (uint32_t)u;
+                    ho = rng_keep(kh, idx, d.drop_p) ? hn * scale : 0.f;
+                    co = rng_keep(kc, idx, d.drop_p) ? cn * scale : 0.f;
+                }
+                st.h_out[(long)b * st.ldh_out + u] = ho;
+                if (st.h_out2) st.h_out2[(long)b * st.ldh_out2 + u] = ho;
+                st.c_out[(long)b * st.ldc_out + u] = co;
+                if (st.h16_out) st.h16_out[(long)b * st.ldh16 + u] = (__bf16)ho;
+                hs[b * HU + uu] = ho;
+            }
+        }
+    }
+
+    if (st.wq) {
+        // partial query projection of this unit group: qpart[group][b][a] = sum_uu h[b,u0+uu] * Wq[a,u0+uu]
+        __syncthreads();
+        float* wqs = part;                            // [A][HU]
+        const int A = st.A;
+        for (int i = threadIdx.x; i < A * HU; i += NTH) wqs[i] = st.wq[(long)(i / HU) * H + u0 + (i % HU)];
+        __syncthreads();
+        float* qp = st.qpart + (long)blockIdx.x * B * A;
+        for (int i = threadIdx.x; i < B * A; i += NTH) {
+            const int b = i / A, a = i % A;
+            float sum = 0.f;
+#pragma unroll
+            for (int uu = 0; uu < HU; ++uu) sum += hs[b * HU + uu] * wqs[a * HU + uu];
+            qp[i] = sum;
+        }
+    }
+}
+
 template <int MT, int BKT>
 __global__ __launch_bounds__(NTH) void lstm_step_fwd_kernel(LstmStepDesc d) {
     using TL = Tile<MT, BKT>;
@@ -205,78 +285,123 @@ __global__ __launch_bounds__(NTH) void lstm_step_fwd_kernel(LstmStepDesc d) {
     }
 
     T2_STAMP(2);
-    const RngKey kh = rng_key(d.seed, st.site_h), kc = rng_key(d.seed, st.site_c);
-    const float scale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        if (m > 0) __syncthreads();
-        // lane holds column r, rows (e&3) + 8*(e>>2) + 4*hk
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-            part[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk) * PP + r] = acc[m][e];
-        __syncthreads();
-        if (threadIdx.x < 32 * HU) {
-            const int bl = threadIdx.x >> 3, uu = threadIdx.x & 7;
-            const int b = m * 32 + bl, u = u0 + uu;
-            if (b < B) {
-                float g4[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float sum = 0.f;
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) sum += part[(w * 32 + bl) * PP + g * 8 + uu];
-                    if (kPrefetch) {
-                        sum += pre_v[kPrefetch ? m : 0][g];
-                    } else {
-                        if (st.pre) sum += st.pre[(long)b * st.ldpre + g * H + u];
-                        if (st.bias1) sum += st.bias1[g * H + u];
-                        if (st.bias2) sum += st.bias2[g * H + u];
-                    }
-                    g4[g] = sum;
-                }
-                const bool active = !st.lengths || st.t < st.lengths[b];
-                float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]), og = sigmoidf_(g4[3]);
-                const float cp = kPrefetch ? cp_v[kPrefetch ? m : 0] : (st.c_prev ? st.c_prev[(long)b * st.ldc_prev + u] : 0.f);
-                float cn = fg * cp + ig * gg;
-                float hn = og * tanhf(cn);
-                if (!active) { ig = fg = gg = og = 0.f; cn = 0.f; hn = 0.f; }
-                if (st.gates) {
-                    float* gp = st.gates + (long)b * st.ldgates + u;
-                    gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
-                }
-                if (st.c_new) st.c_new[(long)b * st.ldc_new + u] = cn;
-                float ho = hn, co = cn;
-                if (d.drop_p > 0.f) {
-                    const uint32_t idx = st.idx_base + (uint32_t)b * st.idx_bstride + (uint32_t)u;
-                    ho = rng_keep(kh, idx, d.drop_p) ? hn * scale : 0.f;
-                    co = rng_keep(kc, idx, d.drop_p) ? cn * scale : 0.f;
-                }
-                st.h_out[(long)b * st.ldh_out + u] = ho;
-                if (st.h_out2) st.h_out2[(long)b * st.ldh_out2 + u] = ho;
-                st.c_out[(long)b * st.ldc_out + u] = co;
-                hs[b * HU + uu] = ho;
-            }
-        }
-    }
-
-    T2_STAMP(3);
-    if (st.wq) {
-        // partial query projection of this unit group: qpart[group][b][a] = sum_uu h[b,u0+uu] * Wq[a,u0+uu]
-        __syncthreads();
-        float* wqs = part;                            // [A][HU]
-        const int A = st.A;
-        for (int i = threadIdx.x; i < A * HU; i += NTH) wqs[i] = st.wq[(long)(i / HU) * H + u0 + (i % HU)];
-        __syncthreads();
-        float* qp = st.qpart + (long)blockIdx.x * B * A;
-        for (int i = threadIdx.x; i < B * A; i += NTH) {
-            const int b = i / A, a = i % A;
-            float sum = 0.f;
-#pragma unroll
-            for (int uu = 0; uu < HU; ++uu) sum += hs[b * HU + uu] * wqs[a * HU + uu];
-            qp[i] = sum;
-        }
-    }
+    lstm_tail<MT, kPrefetch>(d, st, u0, wave, r, hk, acc, part, hs, pre_v, cp_v);
     T2_STAMP(4);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16-operand step (t2_set_precision(1), teacher-forced passes): the recurrent operands come from
+// bf16 shadows — weights cast once per pass ([W_hh | W_ih[:, P:]] as ONE K-contiguous matrix) and
+// the bf16 copies of h / ctx that the producing kernels write next to the fp32 ones — so a step
+// moves half the bytes and the weight slices stay resident in the per-XCD L2s.  fp32 accumulate,
+// fp32 gates / cell state; v_mfma_f32_32x32x16_bf16.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int MT, int BKT> struct Tile16 {
+    static constexpr int P = BKT + 8;                          // bf16 elements: (BKT+8)*2 B = odd number of 16-B slots
+    static constexpr int A_ELEMS = MT * 32 * P, B_ELEMS = 32 * P;
+    static constexpr int QA = MT * 32 * (BKT / 8) / NTH, QB = 32 * (BKT / 8) / NTH;
+    static constexpr int STAGE_FLOATS = (A_ELEMS + B_ELEMS + 1) / 2;
+    static constexpr int SMEM_FLOATS = (STAGE_FLOATS > NW * 32 * PP ? STAGE_FLOATS : NW * 32 * PP);
+};
+
+template <int BKT, int Q, typename RowPtr>
+__device__ __forceinline__ void load_rows16(RowPtr rowptr, int k0, bf16x8 (&regs)[Q]) {
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        const int q = threadIdx.x + i * NTH, row = q / (BKT / 8), k = (q % (BKT / 8)) * 8;
+        bool ok;
+        const __bf16* p = rowptr(row, ok);
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(p + k0 + k);
+        bf16x8 zz;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zz[j] = (__bf16)0.f;
+        regs[i] = ok ? x : zz;
+    }
+}
+template <int BKT, int Q>
+__device__ __forceinline__ void store_rows16(__bf16* __restrict__ lds, const bf16x8 (&regs)[Q]) {
+    constexpr int P = BKT + 8;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        const int q = threadIdx.x + i * NTH, row = q / (BKT / 8), k = (q % (BKT / 8)) * 8;
+        *reinterpret_cast<bf16x8*>(lds + row * P + k) = regs[i];
+    }
+}
+template <int MT, int BKT>
+__device__ __forceinline__ void compute_stage16(const __bf16* __restrict__ As, const __bf16* __restrict__ Bs, int wave, int r, int hk,
+                                                f32x16 (&acc)[MT]) {
+    constexpr int P = BKT + 8;
+#pragma unroll
+    for (int kk = 0; kk < BKT / NW; kk += 16) {
+        const int k = wave * (BKT / NW) + kk + 8 * hk;
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + r * P + k);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + (m * 32 + r) * P + k);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[m], 0, 0, 0);
+        }
+    }
+}
+
+template <int MT, int BKT>
+__global__ __launch_bounds__(NTH) void lstm_step_fwd_bf16_kernel(LstmStepDesc d) {
+    using TL = Tile16<MT, BKT>;
+    const LstmStream& st = d.st[blockIdx.y];
+    const int B = d.B, H = d.H;
+    const int u0 = blockIdx.x * HU;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hk = lane >> 5;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* As = reinterpret_cast<__bf16*>(smem);
+    __bf16* Bs = As + TL::A_ELEMS;
+    float* part = smem;
+    float* hs = smem + TL::SMEM_FLOATS;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+
+    const int nstages = st.k16 / BKT;
+    bf16x8 ra[TL::QA], rb[TL::QB];
+    auto load_stage = [&](int c) {
+        load_rows16<BKT, TL::QA>([&](int row, bool& ok) { ok = row < B; return st.x16 + (long)(ok ? row : 0) * st.ldx16; }, c * BKT, ra);
+        load_rows16<BKT, TL::QB>([&](int n, bool& ok) { ok = true; return st.w16 + (long)((n >> 3) * H + u0 + (n & 7)) * st.ldw16; }, c * BKT, rb);
+    };
+    if (nstages > 0) load_stage(0);
+    constexpr bool kPrefetch = true;
+    float pre_v[MT][4];
+    float cp_v[MT];
+    if (threadIdx.x < 32 * HU) {
+        const int bl = threadIdx.x >> 3, u = u0 + (threadIdx.x & 7);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int b = min(m * 32 + bl, B - 1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v = 0.f;
+                if (st.pre) v += st.pre[(long)b * st.ldpre + g * H + u];
+                if (st.bias1) v += st.bias1[g * H + u];
+                if (st.bias2) v += st.bias2[g * H + u];
+                pre_v[m][g] = v;
+            }
+            cp_v[m] = st.c_prev ? st.c_prev[(long)b * st.ldc_prev + u] : 0.f;
+        }
+    }
+    if (nstages > 0) { store_rows16<BKT, TL::QA>(As, ra); store_rows16<BKT, TL::QB>(Bs, rb); }
+    __syncthreads();
+    for (int c = 0; c < nstages; ++c) {
+        const bool more = c + 1 < nstages;
+        if (more) load_stage(c + 1);
+        compute_stage16<MT, BKT>(As, Bs, wave, r, hk, acc);
+        __syncthreads();
+        if (more) { store_rows16<BKT, TL::QA>(As, ra); store_rows16<BKT, TL::QB>(Bs, rb); __syncthreads(); }
+    }
+    lstm_tail<MT, kPrefetch>(d, st, u0, wave, r, hk, acc, part, hs, pre_v, cp_v);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -331,6 +456,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(LstmBwdPointDes
     dg[H] = dcn * cp * fg * (1.0f - fg);
     dg[2 * H] = dcn * ig * (1.0f - gg * gg);
     dg[3 * H] = dh * tc * og * (1.0f - og);
+    if (st.dg16) {                                   // bf16 copy for the bf16-operand recurrent GEMM of this step
+        __bf16* g16 = st.dg16 + (long)b * 4 * H + u;
+        g16[0] = (__bf16)dg[0]; g16[H] = (__bf16)dg[H]; g16[2 * H] = (__bf16)dg[2 * H]; g16[3 * H] = (__bf16)dg[3 * H];
+    }
     st.dc_state[i] = dcn * fg;
 }
 
@@ -418,6 +547,88 @@ __global__ __launch_bounds__(NTH) void lstm_bwd_gemm_kernel(LstmBwdGemmDesc d) {
     }
 }
 
+// bf16-operand variant of the recurrent-input gradient: A = bf16 copy of dg(t), B = transposed bf16
+// weight shadow wt16[n][k] (K-contiguous), K-split z covers k in [z*kspan, (z+1)*kspan).
+template <int MT>
+__global__ __launch_bounds__(NTH) void lstm_bwd_gemm_bf16_kernel(LstmBwdGemmDesc d) {
+    constexpr int BKT = 256;
+    using TL = Tile16<MT, BKT>;
+    const LstmBwdGemmStream& st = d.st[blockIdx.z];
+    const int B = d.B;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hk = lane >> 5;
+    const int col0 = blockIdx.x * 32;
+    const int kspan = d.H4 / d.KS, kbeg = blockIdx.y * kspan, nstages = kspan / BKT;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* As = reinterpret_cast<__bf16*>(smem);
+    __bf16* Bs = As + TL::A_ELEMS;
+    float* part = smem;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+    bf16x8 ra[TL::QA], rb[TL::QB];
+    auto load_stage = [&](int c) {
+        load_rows16<BKT, TL::QA>([&](int row, bool& ok) { ok = row < B; return st.dg16 + (long)(ok ? row : 0) * d.H4 + kbeg; }, c * BKT, ra);
+        load_rows16<BKT, TL::QB>([&](int n, bool& ok) { ok = true; return st.wt16 + (long)(col0 + n) * d.H4 + kbeg; }, c * BKT, rb);
+    };
+    load_stage(0);
+    store_rows16<BKT, TL::QA>(As, ra); store_rows16<BKT, TL::QB>(Bs, rb);
+    __syncthreads();
+    for (int c = 0; c < nstages; ++c) {
+        const bool more = c + 1 < nstages;
+        if (more) load_stage(c + 1);
+        compute_stage16<MT, BKT>(As, Bs, wave, r, hk, acc);
+        __syncthreads();
+        if (more) { store_rows16<BKT, TL::QA>(As, ra); store_rows16<BKT, TL::QB>(Bs, rb); __syncthreads(); }
+    }
+    float* out = st.part + (long)blockIdx.y * B * d.NC;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (m > 0) __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            part[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk) * PP + r] = acc[m][e];
+        __syncthreads();
+        for (int i = threadIdx.x; i < 32 * 32; i += NTH) {
+            const int bl = i >> 5, c = i & 31, b = m * 32 + bl;
+            if (b < B) {
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sum += part[(w * 32 + bl) * PP + c];
+                out[(long)b * d.NC + col0 + c] = sum;
+            }
+        }
+    }
+}
+
+// dst[r*ldd + c] = bf16(src[r*lds + c])
+__global__ void cast_rows_kernel(const float* __restrict__ src, long lds_, __bf16* __restrict__ dst, long ldd, int R, int C) {
+    const size_t n = (size_t)R * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); const size_t rr = i / C;
+        dst[rr * ldd + c] = (__bf16)src[rr * lds_ + c];
+    }
+}
+// dst[c*ldd + r] = bf16(src[r*lds + c])   (32x32 LDS tiles)
+__global__ void cast_transpose_kernel(const float* __restrict__ src, long lds_, __bf16* __restrict__ dst, long ldd, int R, int C) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int rr = r0 + i, c = c0 + tx;
+        tile[i][tx] = (rr < R && c < C) ? src[(size_t)rr * lds_ + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, rr = r0 + tx;
+        if (c < C && rr < R) dst[(size_t)c * ldd + rr] = (__bf16)tile[tx][i];
+    }
+}
+
 template <int MT, int BKT> size_t fwd_smem() { return (size_t)(Tile<MT, BKT>::FWD_FLOATS + MT * 32 * HU) * sizeof(float); }
 template <int MT, int BKT> size_t bwd_smem() { return (size_t)Tile<MT, BKT>::BWD_FLOATS * sizeof(float); }
 
@@ -463,6 +674,28 @@ int lstm_step_fwd(const LstmStepDesc& d, hipStream_t s) {
     }
     const int MT = (d.B + 31) / 32;
     dim3 grid(d.H / HU, d.nstreams), block(NTH);
+    bool bf = d.st[0].x16 != nullptr;
+    if (bf) {
+        for (int i = 0; i < d.nstreams; ++i)
+            T2_REQUIRE(d.st[i].x16 && d.st[i].w16 && d.st[i].k16 % 256 == 0 && d.st[i].ldx16 % 8 == 0 && d.st[i].ldw16 % 8 == 0 &&
+                       ((uintptr_t)d.st[i].x16 & 15) == 0 && ((uintptr_t)d.st[i].w16 & 15) == 0, "lstm_step: bad bf16 operands");
+        T2_REQUIRE(MT <= 2, "lstm_step: the bf16-operand step supports B <= 64");
+        const bool wide = d.st[0].k16 % 512 == 0 && (d.nstreams < 2 || d.st[1].k16 % 512 == 0);
+        auto go = [&](auto kernel, size_t smem) -> int {
+            T2_TRY_RC(allow_big_lds(kernel, smem));
+            hipLaunchKernelGGL(kernel, grid, block, smem, s, d);
+            return 0;
+        };
+        if (MT <= 1) {
+            if (wide) T2_TRY_RC(go(lstm_step_fwd_bf16_kernel<1, 512>, (size_t)(Tile16<1, 512>::SMEM_FLOATS + 32 * HU) * 4));
+            else T2_TRY_RC(go(lstm_step_fwd_bf16_kernel<1, 256>, (size_t)(Tile16<1, 256>::SMEM_FLOATS + 32 * HU) * 4));
+        } else {
+            if (wide) T2_TRY_RC(go(lstm_step_fwd_bf16_kernel<2, 512>, (size_t)(Tile16<2, 512>::SMEM_FLOATS + 64 * HU) * 4));
+            else T2_TRY_RC(go(lstm_step_fwd_bf16_kernel<2, 256>, (size_t)(Tile16<2, 256>::SMEM_FLOATS + 64 * HU) * 4));
+        }
+        T2_LAUNCH_CHECK();
+        return 0;
+    }
     int kdiv = 0;                                    // gcd-like: every segment width must be a multiple of the stage width
     for (int i = 0; i < d.nstreams; ++i)
         for (int j = 0; j < d.st[i].nseg; ++j) kdiv = kdiv == 0 ? d.st[i].seg[j].k : std::gcd(kdiv, d.st[i].seg[j].k);
@@ -499,7 +732,33 @@ int lstm_bwd_gemm(const LstmBwdGemmDesc& d, hipStream_t s) {
     }
     const int MT = (d.B + 31) / 32;
     dim3 grid(d.NC / 32, d.KS, d.nstreams), block(NTH);
+    if (d.st[0].dg16) {
+        T2_REQUIRE(MT <= 2 && (d.H4 / d.KS) % 256 == 0, "lstm_bwd_gemm: bf16 variant needs B <= 64 and K-split spans of 256");
+        if (MT <= 1) {
+            const size_t smem = (size_t)Tile16<1, 256>::SMEM_FLOATS * 4;
+            hipLaunchKernelGGL(lstm_bwd_gemm_bf16_kernel<1>, grid, block, smem, s, d);
+        } else {
+            const size_t smem = (size_t)Tile16<2, 256>::SMEM_FLOATS * 4;
+            hipLaunchKernelGGL(lstm_bwd_gemm_bf16_kernel<2>, grid, block, smem, s, d);
+        }
+        T2_LAUNCH_CHECK();
+        return 0;
+    }
     LAUNCH_MT(lstm_bwd_gemm_kernel, bwd_smem, d.H4 / d.KS, grid, block, s, d);
+    T2_LAUNCH_CHECK();
+    return 0;
+}
+
+int cast_rows_bf16(const float* src, long ld_src, __bf16* dst, long ld_dst, int R, int C, hipStream_t s) {
+    const size_t n = (size_t)R * C;
+    size_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(cast_rows_kernel, dim3((unsigned)g), dim3(256), 0, s, src, ld_src, dst, ld_dst, R, C);
+    T2_LAUNCH_CHECK();
+    return 0;
+}
+int cast_transpose_bf16(const float* src, long ld_src, __bf16* dst, long ld_dst, int R, int C, hipStream_t s) {
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, s, src, ld_src, dst, ld_dst, R, C);
     T2_LAUNCH_CHECK();
     return 0;
 }

@@ -191,3 +191,38 @@ def test_bf16_operand_mode_stays_close_to_fp32_golden():
     errs = {k: maxabs(v, g[k]) for k, v in zip(("mel", "mel_postnet", "gate", "align"), out)}
     print("bf16-operand max-abs error vs reference fp32:", errs)
     assert errs["mel"] < 0.1 and errs["mel_postnet"] < 0.15 and errs["align"] < 0.1
+
+
+def test_bf16_mode_gradients_track_fp32():
+    """Same batch, same RNG seeds: the bf16-operand mode (large GEMMs and the recurrent step GEMMs in bf16,
+    fp32 accumulate/state) must give gradients close to the fp32 parity path in norm."""
+    from tacotron2_subword_amd import _lib as L
+    from tacotron2_subword_amd.loss_function import Tacotron2Loss
+    hp = hp_for(SMA)
+    B, Tin, Tsub, T = 4, 24, 16, 40
+    batch = recipe.make_batch(hp, B, Tin, Tsub, T)
+    grads, losses = {}, {}
+    for mode in ("f32", "bf16"):
+        m, hps = build_model(SMA, train=True)
+        m.decoder.prenet_dropout = True
+        m._t2_calls, m.decoder._t2_calls = 0, 0
+        x, y = m.parse_batch(batch)
+        L.set_precision(mode)
+        try:
+            loss = Tacotron2Loss()(m(x), y, x)[0]
+            loss.backward()
+        finally:
+            L.set_precision("f32")
+        losses[mode] = float(loss.detach())
+        grads[mode] = {k: p.grad.detach().double().cpu() for k, p in m.named_parameters() if p.grad is not None}
+    assert abs(losses["bf16"] - losses["f32"]) < 0.05 * abs(losses["f32"])
+    worst = {}
+    for k, g32 in grads["f32"].items():
+        n = float(g32.norm())
+        if n < 1e-6:
+            continue
+        rel = float((grads["bf16"][k] - g32).norm()) / n
+        if rel > 0.15:
+            worst[k] = rel
+    print("bf16 vs fp32: loss", losses, "worst relative gradient deviations:", dict(sorted(worst.items(), key=lambda kv: -kv[1])[:5]))
+    assert not worst, worst
