@@ -40,14 +40,16 @@ def decoder_step_flops(hp, B, Tin, Tsub):
                 att_lstm_bwd_gemm=2 * 2 * B * 4 * Ha * (E + Ha), dec_lstm_bwd_gemm=2 * B * 4 * Hd * Hd)
 
 
-def decoder_step_bytes(hp, B, Tin, Tsub):
-    """Algorithmic bytes per launch (fp32): weights once + activations once."""
+def decoder_step_bytes(hp, B, Tin, Tsub, wbytes=4):
+    """Algorithmic bytes per launch: weights once + activations once.  wbytes = 4 (fp32 operands) or 2 (bf16
+    shadows of the recurrent weights / activations; state, gates and pre-activations stay fp32)."""
     P, E, Ha, Hd, A = hp.prenet_dim, hp.encoder_embedding_dim, hp.attention_rnn_dim, hp.decoder_rnn_dim, hp.attention_dim
-    att = 2 * (4 * Ha * (E + Ha) + A * Ha) * 4 + 2 * B * (E + Ha + 4 * Ha + 4 * Ha + 3 * Ha + Ha // 8 * A) * 4
-    dec = 4 * Hd * Hd * 4 + B * (Hd + 4 * Hd + 4 * Hd + 3 * Hd) * 4
+    att = 2 * (4 * Ha * (E + Ha) * wbytes + A * Ha * 4) + 2 * B * ((E + Ha) * wbytes + (4 * Ha + 4 * Ha + 3 * Ha + Ha // 8 * A) * 4)
+    dec = 4 * Hd * Hd * wbytes + B * (Hd * wbytes + (4 * Hd + 4 * Hd + 3 * Hd) * 4)
     attn = B * (Tin + Tsub) * (E + A) * 4
     return dict(att_lstm_fwd=att, dec_lstm_fwd=dec, attention_fwd=attn, attention_bwd=2 * attn,
-                att_lstm_bwd_gemm=2 * 4 * Ha * (E + Ha) * 4, dec_lstm_bwd_gemm=4 * Hd * Hd * 4)
+                att_lstm_bwd_gemm=2 * (4 * Ha * (E + Ha) + B * 4 * Ha) * wbytes + 2 * 8 * B * (E + Ha) * 4,
+                dec_lstm_bwd_gemm=(4 * Hd * Hd + B * 4 * Hd) * wbytes + 8 * B * Hd * 4)
 
 
 def cpu_baseline(B=64, Tin=100, Tsub=60, T=16, reps=1):
@@ -151,7 +153,8 @@ def main():
     if rank == 0:
         prof = L.prof_collect()
         torch.cuda.synchronize()
-        fl, by = decoder_step_flops(hp, B, Tin, Tsub), decoder_step_bytes(hp, B, Tin, Tsub)
+        bf = a.dtype == "bf16"
+        fl, by = decoder_step_flops(hp, B, Tin, Tsub), decoder_step_bytes(hp, B, Tin, Tsub, 2 if bf else 4)
         kernels = {}
         for k, (ms, n) in prof.items():
             if n == 0:
@@ -171,14 +174,16 @@ def main():
                 "att_lstm_bwd_gemm": "lstm_bwd_gemm_grid393216", "dec_lstm_bwd_gemm": "lstm_bwd_gemm_grid131072"}.get(dom)
         if os.path.exists(tpath) and tkey and (B, Tin, Tsub) == (64, 100, 60):
             traffic = json.load(open(tpath)).get(tkey, {}).get("hbm_bytes_per_launch")
-        if dom in fl:
+        # fp32 operands: the recurrent step GEMMs sit just above the fp32-MFMA ridge (AI ~ 26 FLOP/B vs 20) -> MFMA bound;
+        # bf16 operands: 16x the matrix rate -> every per-step kernel is bound by operand delivery (HBM / L2)
+        if dom in fl and not bf:
             roof = dict(kernel=dom, bound="mfma", achieved=kernels[dom]["tflops"], peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(kernels[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
+                        frac=round(kernels[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic if not bf else None,
                         note="fp32 MFMA (v_mfma_f32_32x32x2_f32) peak; algorithmic FLOPs per launch / avg HIP-event duration")
         else:
             roof = dict(kernel=dom, bound="hbm", achieved=kernels[dom]["gbs"], peak=PEAK_HBM_GBS, unit="GB/s",
-                        frac=round(kernels[dom]["gbs"] / PEAK_HBM_GBS, 4), traffic=traffic)
-
+                        frac=round(kernels[dom]["gbs"] / PEAK_HBM_GBS, 4), traffic=traffic if not bf or "attention" in dom else None,
+                        note="algorithmic bytes per launch (DESIGN.md section 3) / avg HIP-event duration")
     if world > 1:
         torch.distributed.barrier()
     if rank != 0:
