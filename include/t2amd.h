@@ -57,6 +57,9 @@ typedef struct t2_dims {
     int loc_kernel;     /* 31 */
     int attention_kind; /* T2_ATTN_* */
     float p_att_dropout, p_dec_dropout, p_prenet_dropout; /* 0.1, 0.1, 0.5 */
+    int n_streams;      /* 2 = BERT_Tacotron2 (phone + sub-word, model.py:142-207); 1 = classic single-stream Tacotron2
+                           (the API GTA.py:6,57-59 expects): decoder_rnn takes [att_h|ctx], projections [dec_h|ctx];
+                           the *_sub weights / memory_sub / align_sub are then ignored (0 is read as 2) */
 } t2_dims;
 
 /* Parameters of Decoder (model.py:128-207), reference state_dict names in comments. */

@@ -93,14 +93,31 @@ def state_dict_spec(hp: dict) -> List[Tuple[str, Tuple[int, ...], str]]:
     return spec
 
 
+def state_dict_spec_single(hp: dict) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """Key/shape list of the classic single-stream Tacotron2 (NVIDIA layout): the dual-stream list minus
+    the sub-word stream and the CLS converters, with decoder_rnn / projections on [h|ctx]."""
+    E, Ha, Hd = hp["encoder_embedding_dim"], hp["attention_rnn_dim"], hp["decoder_rnn_dim"]
+    M = hp["n_mel_channels"] * hp["n_frames_per_step"]
+    out = []
+    for k, shape, kind in state_dict_spec(hp):
+        if "_bert" in k or k.startswith(("embedding_sub", "encoder_sub", "linear_converter")):
+            continue
+        if k == "decoder.decoder_rnn.weight_ih":
+            shape = (4 * Hd, Ha + E)
+        if k in ("decoder.linear_projection.linear_layer.weight", "decoder.gate_layer.linear_layer.weight"):
+            shape = (shape[0], Hd + E)
+        out.append((k, shape, kind))
+    return out
+
+
 def _rng(key: str, seed: int) -> np.random.Generator:
     return np.random.Generator(np.random.PCG64([zlib.crc32(key.encode()), seed]))
 
 
-def make_weights(hp: dict, seed: int = 1234) -> Dict[str, torch.Tensor]:
+def make_weights(hp: dict, seed: int = 1234, single: bool = False) -> Dict[str, torch.Tensor]:
     """Recipe weights: Xavier-like uniform ranges per kind, non-trivial BN statistics."""
     out: Dict[str, torch.Tensor] = {}
-    for key, shape, kind in state_dict_spec(hp):
+    for key, shape, kind in (state_dict_spec_single(hp) if single else state_dict_spec(hp)):
         g = _rng(key, seed)
         if kind == "bn_n":
             out[key] = torch.tensor(int(g.integers(1, 5)), dtype=torch.long)
@@ -185,4 +202,4 @@ def make_rnd(hp: dict, B: int, Tin: int, Tsub: int, T: int, seed: int = 7) -> di
     )
 
 
-__all__ = ["default_hparams", "state_dict_spec", "make_weights", "make_batch", "parse_batch", "make_rnd"]
+__all__ = ["default_hparams", "state_dict_spec", "state_dict_spec_single", "make_weights", "make_batch", "parse_batch", "make_rnd"]

@@ -216,10 +216,15 @@ def lsa_step(query, memory, pm, w_prev, w_cum, mask, P, prefix, score_mask_value
 # decoder
 # --------------------------------------------------------------------------------------
 class DecState:
-    """Decoder.initialize_decoder_states (model.py:223-270)."""
+    """Decoder.initialize_decoder_states (model.py:223-270).  memory_sub=None gives the classic
+    single-stream decoder (the API the reference's stale GTA.py expects; no reference counterpart,
+    so that variant is NOT pinned by golden vectors)."""
 
     def __init__(self, memory, memory_sub, mask, mask_sub, P, hp):
         B, Tin, _ = memory.shape
+        self.single = memory_sub is None
+        if self.single:
+            memory_sub = memory[:, :1]
         Tsub = memory_sub.shape[1]
         Ha, Hd, E = hp["attention_rnn_dim"], hp["decoder_rnn_dim"], hp["encoder_embedding_dim"]
         z = lambda *s: memory.new_zeros(*s)
@@ -229,7 +234,7 @@ class DecState:
         self.wb, self.wcumb, self.ctxb = z(B, Tsub), z(B, Tsub), z(B, E)
         self.memory, self.memory_sub = memory, memory_sub
         self.pm = F.linear(memory, P["decoder.attention_layer.memory_layer.linear_layer.weight"])
-        self.pmb = F.linear(memory_sub, P["decoder.attention_layer_bert.memory_layer.linear_layer.weight"])
+        self.pmb = None if self.single else F.linear(memory_sub, P["decoder.attention_layer_bert.memory_layer.linear_layer.weight"])
         self.mask, self.mask_sub = mask, mask_sub
         self.sma = hp["attention"] == "StepwiseMonotonicAttention"
         if self.sma:                                # attention.py:324-328
@@ -246,6 +251,8 @@ def decode_step(st: DecState, xp: Tensor, xb: Tensor, P, hp, rnd=None, t: int = 
                              P["decoder.attention_rnn.bias_ih"], P["decoder.attention_rnn.bias_hh"])
     st.ah = _drop(st.ah, _get(rnd, "att_h_keep", t), pa)
     st.ac = _drop(st.ac, _get(rnd, "att_c_keep", t), pa)
+    if st.single:
+        return _decode_step_single(st, P, hp, rnd, t, trace)
     st.ahb, st.acb = lstm_cell(torch.cat((xb, st.ctxb), -1), st.ahb, st.acb,
                                P["decoder.attention_rnn_bert.weight_ih"], P["decoder.attention_rnn_bert.weight_hh"],
                                P["decoder.attention_rnn_bert.bias_ih"], P["decoder.attention_rnn_bert.bias_hh"])
@@ -282,6 +289,27 @@ def decode_step(st: DecState, xp: Tensor, xb: Tensor, P, hp, rnd=None, t: int = 
     return mel, gate, st.w, st.wb
 
 
+def _decode_step_single(st, P, hp, rnd, t, trace):
+    """Classic single-stream remainder of Decoder.decode: attention, decoder LSTM on [att_h|ctx],
+    projections on [dec_h|ctx]."""
+    pd = hp["p_decoder_dropout"]
+    if st.sma:
+        st.ctx, st.align = sma_step(st.ah, st.memory, st.pm, st.align, st.mask, P, "decoder.attention_layer", _get(rnd, "sma_noise", t))
+        st.w = st.align
+    else:
+        st.ctx, st.w = lsa_step(st.ah, st.memory, st.pm, st.w, st.wcum, st.mask, P, "decoder.attention_layer")
+    st.wcum = st.wcum + st.w
+    st.dh, st.dc = lstm_cell(torch.cat((st.ah, st.ctx), -1), st.dh, st.dc,
+                             P["decoder.decoder_rnn.weight_ih"], P["decoder.decoder_rnn.weight_hh"],
+                             P["decoder.decoder_rnn.bias_ih"], P["decoder.decoder_rnn.bias_hh"])
+    st.dh = _drop(st.dh, _get(rnd, "dec_h_keep", t), pd)
+    st.dc = _drop(st.dc, _get(rnd, "dec_c_keep", t), pd)
+    dhc = torch.cat((st.dh, st.ctx), dim=1)
+    mel = F.linear(dhc, P["decoder.linear_projection.linear_layer.weight"], P["decoder.linear_projection.linear_layer.bias"])
+    gate = F.linear(dhc, P["decoder.gate_layer.linear_layer.weight"], P["decoder.gate_layer.linear_layer.bias"])
+    return mel, gate, st.w, st.w
+
+
 def decoder_forward(memory, memory_sub, mels, mem_lengths, sub_lengths, P, hp, rnd=None, trace=None):
     """Decoder.forward (model.py:392-428), teacher forced.  mels: [B,80,T]."""
     B = memory.shape[0]
@@ -292,10 +320,11 @@ def decoder_forward(memory, memory_sub, mels, mem_lengths, sub_lengths, P, hp, r
     k = lambda name, i: _get(rnd, name, i)
     xp = prenet(x[:T], P["decoder.prenet.layers.0.linear_layer.weight"], P["decoder.prenet.layers.1.linear_layer.weight"],
                 k("prenet_keep", 0), k("prenet_keep", 1))
-    xb = prenet(x[:T], P["decoder.prenet_bert.layers.0.linear_layer.weight"], P["decoder.prenet_bert.layers.1.linear_layer.weight"],
-                k("prenet_bert_keep", 0), k("prenet_bert_keep", 1))
+    single = memory_sub is None
+    xb = xp if single else prenet(x[:T], P["decoder.prenet_bert.layers.0.linear_layer.weight"],
+                                  P["decoder.prenet_bert.layers.1.linear_layer.weight"], k("prenet_bert_keep", 0), k("prenet_bert_keep", 1))
     st = DecState(memory, memory_sub, ~get_mask_from_lengths(mem_lengths, memory.shape[1]),
-                  ~get_mask_from_lengths(sub_lengths, memory_sub.shape[1]), P, hp)
+                  None if single else ~get_mask_from_lengths(sub_lengths, memory_sub.shape[1]), P, hp)
     mel_o, gate_o, al, alb = [], [], [], []
     for t in range(T):
         m, g, w, wb = decode_step(st, xp[t], xb[t], P, hp, rnd, t, trace)
@@ -311,6 +340,7 @@ def decoder_inference(memory, memory_sub, P, hp, max_decoder_steps=None, gate_th
     supports: the stop test at :461,480 takes bool() of a [B,1] tensor).  Optional
     per-step prenet keep masks ([steps,2,1,256]) replay the always-on prenet dropout."""
     assert memory.shape[0] == 1
+    single = memory_sub is None
     mds = hp["max_decoder_steps"] if max_decoder_steps is None else max_decoder_steps
     thr = hp["gate_threshold"] if gate_threshold is None else gate_threshold
     st = DecState(memory, memory_sub, None, None, P, hp)
@@ -322,7 +352,8 @@ def decoder_inference(memory, memory_sub, P, hp, max_decoder_steps=None, gate_th
         kp = (None, None) if prenet_keep is None else (prenet_keep[i, 0], prenet_keep[i, 1])
         kb = (None, None) if prenet_bert_keep is None else (prenet_bert_keep[i, 0], prenet_bert_keep[i, 1])
         xp = prenet(x, P["decoder.prenet.layers.0.linear_layer.weight"], P["decoder.prenet.layers.1.linear_layer.weight"], *kp)
-        xb = prenet(x, P["decoder.prenet_bert.layers.0.linear_layer.weight"], P["decoder.prenet_bert.layers.1.linear_layer.weight"], *kb)
+        xb = xp if single else prenet(x, P["decoder.prenet_bert.layers.0.linear_layer.weight"],
+                                      P["decoder.prenet_bert.layers.1.linear_layer.weight"], *kb)
         m, g, w, wb = decode_step(st, xp, xb, P, hp)
         mel_o.append(m); gate_o.append(g); al.append(w); alb.append(wb)
         if torch.sigmoid(g).item() > thr:
@@ -387,3 +418,27 @@ def loss(y_pred, y):
     mel_loss = F.mse_loss(mel_o, mel_t) + F.mse_loss(post_o, mel_t)
     gate_loss = F.binary_cross_entropy_with_logits(gate_o.reshape(-1, 1), gate_t.reshape(-1, 1))
     return mel_loss + gate_loss, mel_loss, gate_loss
+
+
+def forward_single(P, hp, x, training: bool = False, rnd=None, new_stats=None):
+    """Classic single-stream Tacotron2.forward (the API of GTA.py:57-59): x = (text, text_lengths, mels,
+    max_len, output_lengths) -> [mel, mel_postnet, gate, align].  No reference counterpart."""
+    text, tl, mels, _, ol = x
+    emb = F.embedding(text, P["embedding.weight"]).transpose(1, 2)
+    mem = encoder(emb, tl, P, "encoder", training, _get(rnd, "enc_keep"), new_stats)
+    mel, gate, al, _ = decoder_forward(mem, None, mels, tl, None, P, hp, rnd)
+    post = mel + postnet(mel, P, training, _get(rnd, "post_keep"), new_stats)
+    if hp["mask_padding"] and ol is not None:
+        m = ~get_mask_from_lengths(ol, mel.shape[2])
+        mel.data.masked_fill_(m[:, None, :].expand_as(mel), 0.0)
+        post.data.masked_fill_(m[:, None, :].expand_as(post), 0.0)
+        gate.data.masked_fill_(m, 1e3)
+    return [mel, post, gate, al]
+
+
+def inference_single(P, hp, ids, **kw):
+    emb = F.embedding(ids, P["embedding.weight"]).transpose(1, 2)
+    mem = encoder(emb, None, P, "encoder", False)
+    mel, gate, al, _, flag = decoder_inference(mem, None, P, hp, **kw)
+    post = mel + postnet(mel, P, False)
+    return [mel, post, gate, al, flag]

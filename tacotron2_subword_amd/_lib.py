@@ -27,7 +27,7 @@ class Dims(C.Structure):
     _fields_ = [("n_mel", C.c_int), ("prenet_dim", C.c_int), ("enc_dim", C.c_int), ("att_rnn_dim", C.c_int),
                 ("dec_rnn_dim", C.c_int), ("att_dim", C.c_int), ("loc_filters", C.c_int), ("loc_kernel", C.c_int),
                 ("attention_kind", C.c_int), ("p_att_dropout", C.c_float), ("p_dec_dropout", C.c_float),
-                ("p_prenet_dropout", C.c_float)]
+                ("p_prenet_dropout", C.c_float), ("n_streams", C.c_int)]
 
 
 class AttentionWeights(C.Structure):
@@ -212,17 +212,18 @@ def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def dims_from_hparams(hp) -> Dims:
+def dims_from_hparams(hp, n_streams: int = 2) -> Dims:
     g = (lambda k: hp[k]) if isinstance(hp, dict) else (lambda k: getattr(hp, k))
     kind = ATTN_SMA if g("attention") == "StepwiseMonotonicAttention" else ATTN_LSA
     return Dims(int(g("n_mel_channels")) * int(g("n_frames_per_step")), int(g("prenet_dim")), int(g("encoder_embedding_dim")),
                 int(g("attention_rnn_dim")), int(g("decoder_rnn_dim")), int(g("attention_dim")),
                 int(g("attention_location_n_filters")), int(g("attention_location_kernel_size")), kind,
-                float(g("p_attention_dropout")), float(g("p_decoder_dropout")), 0.5)
+                float(g("p_attention_dropout")), float(g("p_decoder_dropout")), 0.5, n_streams)
 
 
-def decoder_weights(P: dict, kind: int, prefix: str = "decoder.") -> DecoderWeights:
-    """Pack device pointers of a (reference-keyed) state dict; the tensors must outlive the call."""
+def decoder_weights(P: dict, kind: int, prefix: str = "decoder.", single: bool = False) -> DecoderWeights:
+    """Pack device pointers of a (reference-keyed) state dict; the tensors must outlive the call.
+    single: classic one-stream decoder (no *_bert modules)."""
     p = lambda k: ptr(P[prefix + k])
     lstm = lambda n: LstmWeights(p(n + ".weight_ih"), p(n + ".weight_hh"), p(n + ".bias_ih"), p(n + ".bias_hh"))
 
@@ -233,9 +234,12 @@ def decoder_weights(P: dict, kind: int, prefix: str = "decoder.") -> DecoderWeig
         return AttentionWeights(p(n + ".query_layer.linear_layer.weight"), p(n + ".memory_layer.linear_layer.weight"),
                                 p(n + ".v.linear_layer.weight"), p(n + ".location_layer.location_conv.conv.weight"),
                                 p(n + ".location_layer.location_dense.linear_layer.weight"))
+    none_l, none_a = LstmWeights(None, None, None, None), AttentionWeights(None, None, None, None, None)
     return DecoderWeights(p("prenet.layers.0.linear_layer.weight"), p("prenet.layers.1.linear_layer.weight"),
-                          p("prenet_bert.layers.0.linear_layer.weight"), p("prenet_bert.layers.1.linear_layer.weight"),
-                          lstm("attention_rnn"), lstm("attention_rnn_bert"), attn("attention_layer"), attn("attention_layer_bert"),
+                          None if single else p("prenet_bert.layers.0.linear_layer.weight"),
+                          None if single else p("prenet_bert.layers.1.linear_layer.weight"),
+                          lstm("attention_rnn"), none_l if single else lstm("attention_rnn_bert"),
+                          attn("attention_layer"), none_a if single else attn("attention_layer_bert"),
                           lstm("decoder_rnn"), p("linear_projection.linear_layer.weight"), p("linear_projection.linear_layer.bias"),
                           p("gate_layer.linear_layer.weight"), p("gate_layer.linear_layer.bias"))
 
@@ -268,15 +272,23 @@ def _lsa_keys():
 DECODER_PARAM_KEYS_LSA = _lsa_keys()
 
 
-def decoder_grads(G: dict, prefix: str = "decoder.") -> DecoderGrads:
+def decoder_param_keys(kind: int, single: bool = False):
+    keys = DECODER_PARAM_KEYS_SMA if kind == ATTN_SMA else DECODER_PARAM_KEYS_LSA
+    return [k for k in keys if "_bert" not in k] if single else keys
+
+
+def decoder_grads(G: dict, prefix: str = "decoder.", single: bool = False) -> DecoderGrads:
     """Pack pointers of gradient buffers keyed like the weights (SMA parameter set)."""
     p = lambda k: ptr(G[prefix + k])
     lstm = lambda n: LstmGrads(p(n + ".weight_ih"), p(n + ".weight_hh"), p(n + ".bias_ih"), p(n + ".bias_hh"))
     attn = lambda n: AttentionGrads(p(n + ".query_layer.linear_layer.weight"), p(n + ".memory_layer.linear_layer.weight"),
                                     p(n + ".v.weight"), None, None)
+    none_l, none_a = LstmGrads(None, None, None, None), AttentionGrads(None, None, None, None, None)
     return DecoderGrads(p("prenet.layers.0.linear_layer.weight"), p("prenet.layers.1.linear_layer.weight"),
-                        p("prenet_bert.layers.0.linear_layer.weight"), p("prenet_bert.layers.1.linear_layer.weight"),
-                        lstm("attention_rnn"), lstm("attention_rnn_bert"), attn("attention_layer"), attn("attention_layer_bert"),
+                        None if single else p("prenet_bert.layers.0.linear_layer.weight"),
+                        None if single else p("prenet_bert.layers.1.linear_layer.weight"),
+                        lstm("attention_rnn"), none_l if single else lstm("attention_rnn_bert"),
+                        attn("attention_layer"), none_a if single else attn("attention_layer_bert"),
                         lstm("decoder_rnn"), p("linear_projection.linear_layer.weight"), p("linear_projection.linear_layer.bias"),
                         p("gate_layer.linear_layer.weight"), p("gate_layer.linear_layer.bias"))
 

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
         if (h < nh) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const float* mp = st.memory + (long)b * Tin * E + dd;
-#pragma unroll 4
+#pragma unroll 8
             for (int j = lo + h; j < hi; j += nh) {
                 const f32x4 mv = *reinterpret_cast<const f32x4*>(mp + (long)j * E);
                 acc += an[j] * mv;
@@ -218,8 +218,9 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
 //   dq_k   = sum_j dpre_jk ; dv_k += sum_j de_j u_jk ; dpm_jk += dpre_jk
 //   carry_j <- g_j p_j + g_{j+1} (1 - p_j)                            gradient on a_{t-1}[j]
 // ---------------------------------------------------------------------------------------------
-constexpr int NTB = 512;     // backward keeps per-lane dq/dv accumulators: 8 waves leave it 256 VGPRs
+constexpr int NTB = 512;     // 8 waves (1024 threads spill at 128 VGPRs); MAXI (= ceil(A/64)) sizes the per-lane dq/dv accumulators
 
+template <int MAXI>
 __global__ __launch_bounds__(NTB) void attention_step_bwd_kernel(AttnBwdDesc d) {
     const AttnBwdStream& st = d.st[blockIdx.y];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -300,7 +301,6 @@ __global__ __launch_bounds__(NTB) void attention_step_bwd_kernel(AttnBwdDesc d) 
     // energies backward: 16 lanes per position, each lane owns channels sub*4 + 64*i
     {
         const int gid = tid >> 4, sub = tid & 15;
-        constexpr int MAXI = 4;                                   // A <= 256
         float dq[MAXI][4], dv[MAXI][4];
 #pragma unroll
         for (int i = 0; i < MAXI; ++i)
@@ -388,11 +388,15 @@ int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s) {
     const int Tp = (Tmax + 3) & ~3;
     const size_t smem = ((size_t)d.E + 2 * d.A + (Tp + 4) + 2 * Tp + 2 * (NTB / 16) * (size_t)d.A) * sizeof(float);
     T2_REQUIRE(smem <= 160 * 1024, "attention_bwd: T_in too long for LDS (%zu bytes)", smem);
-    if (smem > 64 * 1024) {
-        T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_step_bwd_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if (d.A <= 128) {
+        if (smem > 64 * 1024)
+            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_step_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(attention_step_bwd_kernel<2>, dim3(d.B, d.nstreams), dim3(NTB), smem, s, d);
+    } else {
+        if (smem > 64 * 1024)
+            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_step_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(attention_step_bwd_kernel<4>, dim3(d.B, d.nstreams), dim3(NTB), smem, s, d);
     }
-    hipLaunchKernelGGL(attention_step_bwd_kernel, dim3(d.B, d.nstreams), dim3(NTB), smem, s, d);
     T2_LAUNCH_CHECK();
     return 0;
 }

@@ -53,15 +53,16 @@ struct ProfScope {
 namespace {
 
 struct Sizes {
-    int B, T, Tin, Tsub, M, P, E, Ha, Hd, A, WD, WO;
+    int B, T, Tin, Tsub, M, P, E, Ha, Hd, A, WD, WO, NS;     // NS: attention streams (2 = BERT_Tacotron2, 1 = classic Tacotron2)
 };
 
 Sizes sizes_of(const t2_dims& d, int B, int T, int Tin, int Tsub) {
     Sizes z{};
     z.B = B; z.T = T; z.Tin = Tin; z.Tsub = Tsub;
     z.M = d.n_mel; z.P = d.prenet_dim; z.E = d.enc_dim; z.Ha = d.att_rnn_dim; z.Hd = d.dec_rnn_dim; z.A = d.att_dim;
-    z.WD = 2 * z.Ha + 2 * z.E;
-    z.WO = z.Hd + 2 * z.E;
+    z.NS = d.n_streams == 1 ? 1 : 2;
+    z.WD = z.NS * (z.Ha + z.E);
+    z.WO = z.Hd + z.NS * z.E;
     return z;
 }
 
@@ -150,7 +151,7 @@ bool use_bf16_steps(const t2_dims& d, const Sizes& z) {
 int cast_shadows(const t2_dims& d, const t2_decoder_weights& w, const Sizes& z, const t2_decoder_layout& L, float* ws, hipStream_t s) {
     auto P16 = [&](size_t off) { return reinterpret_cast<__bf16*>(ws + off); };
     const long K = z.Ha + z.E, ldi = z.P + z.E;
-    for (int st = 0; st < 2; ++st) {
+    for (int st = 0; st < z.NS; ++st) {
         const t2_lstm_weights& lw = st ? w.att_sub : w.att;
         __bf16* f = P16(st ? L.w16as : L.w16a);
         T2_TRY(cast_rows_bf16(lw.w_hh, z.Ha, f, K, 4 * z.Ha, z.Ha, s));
@@ -167,10 +168,10 @@ int cast_shadows(const t2_dims& d, const t2_decoder_weights& w, const Sizes& z, 
 int att_lstm_step(const Dec& c, int t) {
     const Sizes& z = c.z; const t2_decoder_layout& L = c.L;
     LstmStepDesc d{};
-    d.nstreams = 2; d.B = z.B; d.H = z.Ha; d.seed = c.seed;
+    d.nstreams = z.NS; d.B = z.B; d.H = z.Ha; d.seed = c.seed;
     d.drop_p = c.training ? c.d.p_att_dropout : 0.f;
     float* DIN = c.P(L.din);
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < z.NS; ++s) {
         LstmStream& st = d.st[s];
         const t2_lstm_weights& lw = s ? c.w.att_sub : c.w.att;
         const int hoff = s ? z.Ha + z.E : 0, coff = hoff + z.Ha;
@@ -210,11 +211,11 @@ int att_lstm_step(const Dec& c, int t) {
 int attention_step(const Dec& c, int t) {
     const Sizes& z = c.z; const t2_decoder_layout& L = c.L;
     AttnStepDesc d{};
-    d.nstreams = 2; d.B = z.B; d.A = z.A; d.E = z.E; d.kind = c.d.attention_kind;
+    d.nstreams = z.NS; d.B = z.B; d.A = z.A; d.E = z.E; d.kind = c.d.attention_kind;
     d.F = c.d.loc_filters; d.Kc = c.d.loc_kernel; d.seed = c.seed; d.first = t == 0;
     d.noise_std = (c.training && d.kind == T2_ATTN_SMA) ? 2.0f : 0.f;     // attention.py:315,346-348
     d.mask_value = -INFINITY;                                              // attention.py:37,306
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < z.NS; ++s) {
         AttnStream& st = d.st[s];
         const t2_attention_weights& aw = s ? c.w.attn_sub : c.w.attn;
         const int Tin = s ? z.Tsub : z.Tin;
@@ -234,9 +235,9 @@ int attention_step(const Dec& c, int t) {
             st.wcum_prev = t > 0 ? wc + (long)(t - 1) * Tin : nullptr; st.ldwcum_prev = ldA;
             st.wcum_out = wc + (long)t * Tin; st.ldwcum_out = ldA;
         }
-        st.ctx1 = c.P(L.din) + c.R(t) * z.WD + (s ? 2 * z.Ha + z.E : z.Ha); st.ldctx1 = z.WD;
+        st.ctx1 = c.P(L.din) + c.R(t) * z.WD + ((s ? z.Ha + z.E : 0) + z.Ha); st.ldctx1 = z.WD;
         st.ctx2 = c.P(L.dout) + c.R(t) * z.WO + z.Hd + (s ? z.E : 0); st.ldctx2 = z.WO;
-        if (c.use16) { st.ctx16 = c.P16(L.din16) + c.R(t) * z.WD + (s ? 2 * z.Ha + z.E : z.Ha); st.ldctx16 = z.WD; }
+        if (c.use16) { st.ctx16 = c.P16(L.din16) + c.R(t) * z.WD + ((s ? z.Ha + z.E : 0) + z.Ha); st.ldctx16 = z.WD; }
         st.v = aw.v; st.loc_conv = aw.loc_conv; st.loc_dense = aw.loc_dense;
         st.site_noise = s ? T2_SITE_NOISE_SUB : T2_SITE_NOISE;
         st.idx_base = (uint32_t)(c.R(t) * Tin); st.idx_bstride = (uint32_t)Tin;          // logical [T,B,Tin]
@@ -297,6 +298,7 @@ int processed_memory(const Dec& c) {
     const Sizes& z = c.z;
     GemmDesc g = linear(c.memory, z.E, c.w.attn.wm, z.E, c.P(c.L.pm), z.A, z.B * z.Tin, z.A, z.E);
     T2_TRY(gemm(g, c.s));
+    if (z.NS == 1) return 0;
     GemmDesc h = linear(c.memory_sub, z.E, c.w.attn_sub.wm, z.E, c.P(c.L.pms), z.A, z.B * z.Tsub, z.A, z.E);
     return gemm(h, c.s);
 }
@@ -407,8 +409,8 @@ int att_bwd_step(const Bwd& c, int t) {
     const bool first = t == z.T - 1;
     // 1. attention backward (needs dctx(t) incl. the recurrent partials of step t+1)
     AttnBwdDesc ab{};
-    ab.nstreams = 2; ab.B = z.B; ab.A = z.A; ab.E = z.E; ab.first = first;
-    for (int s = 0; s < 2; ++s) {
+    ab.nstreams = z.NS; ab.B = z.B; ab.A = z.A; ab.E = z.E; ab.first = first;
+    for (int s = 0; s < z.NS; ++s) {
         AttnBwdStream& st = ab.st[s];
         const int Tin = s ? z.Tsub : z.Tin;
         const int hoff = s ? z.Ha + z.E : 0, coff = hoff + z.Ha;
@@ -433,9 +435,9 @@ int att_bwd_step(const Bwd& c, int t) {
     { ProfScope ps(PK_ATTN_BWD, c.s); T2_TRY(attention_step_bwd(ab, c.s)); }
     // 2. LSTM pointwise backward
     LstmBwdPointDesc p{};
-    p.nstreams = 2; p.B = z.B; p.H = z.Ha; p.seed = c.a.seed; p.first = first;
+    p.nstreams = z.NS; p.B = z.B; p.H = z.Ha; p.seed = c.a.seed; p.first = first;
     p.drop_p = c.a.training ? c.d.p_att_dropout : 0.f;
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < z.NS; ++s) {
         LstmBwdStream& st = p.st[s];
         const int hoff = s ? z.Ha + z.E : 0;
         st.dh1 = c.S(c.BL.ddin) + c.R(t) * z.WD + hoff; st.lddh1 = z.WD;
@@ -455,8 +457,8 @@ int att_bwd_step(const Bwd& c, int t) {
     if (t == 0) return 0;
     // 3. recurrent-input gradients of this step: dg(t) . [W_ih[:, P:] | W_hh]  ->  partials for step t-1
     LstmBwdGemmDesc g{};
-    g.nstreams = 2; g.B = z.B; g.H4 = 4 * z.Ha; g.KS = ks; g.NC = NC;
-    for (int s = 0; s < 2; ++s) {
+    g.nstreams = z.NS; g.B = z.B; g.H4 = 4 * z.Ha; g.KS = ks; g.NC = NC;
+    for (int s = 0; s < z.NS; ++s) {
         const t2_lstm_weights& lw = s ? c.w.att_sub : c.w.att;
         g.st[s].dg = p.st[s].dg; g.st[s].lddg = p.st[s].lddg;
         g.st[s].seg[0] = LstmBwdSeg{lw.w_ih + z.P, (long)(z.P + z.E), z.E};
@@ -508,10 +510,10 @@ int t2_decoder_forward(const t2_dims* dims, const t2_decoder_weights* w, const t
     // teacher inputs and both prenets over all frames (model.py:407-413)
     T2_TRY(teacher_inputs(a->mels, c.P(L.x), z.B, z.M, z.T, c.s));
     T2_TRY(prenet(c, false, c.P(L.x), z.M, BT, c.P(L.p1), c.P(L.p2), z.P, 0, 0));      // rows time-major: (t,b)
-    T2_TRY(prenet(c, true, c.P(L.x), z.M, BT, c.P(L.p1s), c.P(L.p2s), z.P, 0, 0));
+    if (z.NS == 2) T2_TRY(prenet(c, true, c.P(L.x), z.M, BT, c.P(L.p1s), c.P(L.p2s), z.P, 0, 0));
     T2_TRY(processed_memory(c));                                    // model.py:258,261
     // hoisted input half of both attention LSTMs:  P2 . W_ih[:, :P]^T + b_ih + b_hh
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < z.NS; ++s) {
         const t2_lstm_weights& lw = s ? w->att_sub : w->att;
         GemmDesc g = linear(c.P(s ? L.p2s : L.p2), z.P, lw.w_ih, z.P + z.E, c.P(s ? L.preas : L.prea), 4 * z.Ha, BT, 4 * z.Ha, z.P);
         g.bias1 = lw.b_ih; g.bias2 = lw.b_hh;
@@ -586,7 +588,7 @@ int t2_decoder_backward(const t2_dims* dims, const t2_decoder_weights* w, const 
     }
     // ---- attention LSTMs + attention, reverse time
     for (int t = z.T - 1; t >= 0; --t) T2_TRY(att_bwd_step(c, t));
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < z.NS; ++s) {
         const t2_lstm_weights& lw = s ? w->att_sub : w->att;
         const t2_lstm_grads& lg = s ? g->att_sub : g->att;
         const t2_attention_weights& aw = s ? w->attn_sub : w->attn;
@@ -662,7 +664,7 @@ int t2_decoder_infer(const t2_dims* dims, const t2_decoder_weights* w, const t2_
         const long ldx = t == 0 ? z.M : (long)T * z.M;
         const uint32_t base = (uint32_t)(c.R(t) * z.P), mstride = (uint32_t)z.P;
         T2_TRY(prenet(c, false, X, ldx, z.B, c.P(L.p1) + c.R(t) * z.P, c.P(L.p2) + c.R(t) * z.P, z.P, base, mstride));
-        T2_TRY(prenet(c, true, X, ldx, z.B, c.P(L.p1s) + c.R(t) * z.P, c.P(L.p2s) + c.R(t) * z.P, z.P, base, mstride));
+        if (z.NS == 2) T2_TRY(prenet(c, true, X, ldx, z.B, c.P(L.p1s) + c.R(t) * z.P, c.P(L.p2s) + c.R(t) * z.P, z.P, base, mstride));
         T2_TRY(att_lstm_step(c, t));
         T2_TRY(attention_step(c, t));
         T2_TRY(dec_lstm_step(c, t));

@@ -119,19 +119,20 @@ class _DecoderFn(torch.autograd.Function):
         dec, keys = cfg["decoder"], cfg["keys"]
         P = {"decoder." + k: p.detach() for k, p in zip(keys, params)}
         dims = dec.dims
-        W = L.decoder_weights(P, dims.attention_kind)
-        memory, memory_sub, mels = memory.contiguous(), memory_sub.contiguous(), mels.contiguous()
+        W = L.decoder_weights(P, dims.attention_kind, single=dec.single)
+        memory, mels = memory.contiguous(), mels.contiguous()
+        memory_sub = None if memory_sub is None else memory_sub.contiguous()
         dp = ops.decoder_forward(W, dims, memory, memory_sub, mem_lengths, sub_lengths, mels,
                                  training=cfg["training"], prenet_dropout=cfg["prenet_dropout"], seed=cfg["seed"])
         ctx.cfg, ctx.dp, ctx.P, ctx.W = cfg, dp, P, W
-        ctx.save_for_backward(memory, memory_sub)
+        ctx.save_for_backward(*((memory,) if memory_sub is None else (memory, memory_sub)))
         ctx.set_materialize_grads(False)
         return dp.mel, dp.gate, dp.align, dp.align_sub
 
     @staticmethod
     def backward(ctx, d_mel, d_gate, d_align, d_align_sub):
         cfg, dp = ctx.cfg, ctx.dp
-        memory, memory_sub = ctx.saved_tensors
+        memory, memory_sub = (ctx.saved_tensors + (None,))[:2]
         c = lambda g, ref: torch.zeros_like(ref) if g is None else g.contiguous()
         cz = lambda g: None if g is None else g.contiguous()
         G, dm, dms = ops.decoder_backward(ctx.W, ctx.P, cfg["decoder"].dims, dp, memory, memory_sub, c(d_mel, dp.mel),
@@ -146,9 +147,11 @@ class Decoder(nn.Module):
     """model.py:128-492.  Holds the parameters under the reference's names; the step loop lives in
     csrc/ (lstm.hip, attention.hip, c_api.hip)."""
 
-    def __init__(self, hparams):
+    def __init__(self, hparams, single=False):
         super().__init__()
         hp = hparams
+        self.single = bool(single)          # classic one-stream decoder (Tacotron2 class below)
+        ns = 1 if single else 2
         self.n_mel_channels, self.n_frames_per_step = hp.n_mel_channels, hp.n_frames_per_step
         self.encoder_embedding_dim, self.attention_rnn_dim = hp.encoder_embedding_dim, hp.attention_rnn_dim
         self.decoder_rnn_dim, self.prenet_dim = hp.decoder_rnn_dim, hp.prenet_dim
@@ -157,9 +160,11 @@ class Decoder(nn.Module):
         E, Ha, Hd, Pn = hp.encoder_embedding_dim, hp.attention_rnn_dim, hp.decoder_rnn_dim, hp.prenet_dim
         M = hp.n_mel_channels * hp.n_frames_per_step
         self.prenet = Prenet(M, [Pn, Pn])
-        self.prenet_bert = Prenet(M, [Pn, Pn])
+        if not single:
+            self.prenet_bert = Prenet(M, [Pn, Pn])
         self.attention_rnn = nn.LSTMCell(Pn + E, Ha)
-        self.attention_rnn_bert = nn.LSTMCell(Pn + E, Ha)
+        if not single:
+            self.attention_rnn_bert = nn.LSTMCell(Pn + E, Ha)
         # The reference builds attention_layer_bert only for SMA and then uses it unconditionally
         # (model.py:158-191 vs :261,356); here both streams always get their module.
         att_cls = StepwiseMonotonicAttention if hp.attention == "StepwiseMonotonicAttention" else LocationSensitiveAttention
@@ -169,20 +174,20 @@ class Decoder(nn.Module):
         print("Use SMA" if att_cls is StepwiseMonotonicAttention else "Use LSA")
         args = (Ha, E, hp.attention_dim, hp.attention_location_n_filters, hp.attention_location_kernel_size)
         self.attention_layer = att_cls(*args)
-        self.attention_layer_bert = att_cls(*args)
-        self.decoder_rnn = nn.LSTMCell(2 * Ha + 2 * E, Hd, 1)
-        self.decoder_rnn_bert = nn.LSTMCell(Ha + E, Hd, 1)      # dead in the reference too (model.py:197-199, :375-378)
-        self.linear_projection = LinearNorm(Hd + 2 * E, M)
-        self.gate_layer = LinearNorm(Hd + 2 * E, 1, bias=True, w_init_gain="sigmoid")
-        self.dims = L.dims_from_hparams(hp)
+        if not single:
+            self.attention_layer_bert = att_cls(*args)
+        self.decoder_rnn = nn.LSTMCell(ns * (Ha + E), Hd, 1)
+        if not single:
+            self.decoder_rnn_bert = nn.LSTMCell(Ha + E, Hd, 1)  # dead in the reference too (model.py:197-199, :375-378)
+        self.linear_projection = LinearNorm(Hd + ns * E, M)
+        self.gate_layer = LinearNorm(Hd + ns * E, 1, bias=True, w_init_gain="sigmoid")
+        self.dims = L.dims_from_hparams(hp, ns)
         self.prenet_dropout = True          # model.py:23 (always on); tests switch it off for deterministic parity
         self.base_seed, self._calls = int(getattr(hp, "seed", 1234)), 0
 
     # -- helpers ---------------------------------------------------------------------------
     def _param_keys(self):
-        if self.dims.attention_kind == L.ATTN_SMA:
-            return L.DECODER_PARAM_KEYS_SMA
-        return L.DECODER_PARAM_KEYS_LSA
+        return L.decoder_param_keys(self.dims.attention_kind, self.single)
 
     def _params(self):
         sd = dict(self.named_parameters())
@@ -193,7 +198,7 @@ class Decoder(nn.Module):
 
     def _weights(self):
         P = {"decoder." + k: v.detach() for k, v in self.named_parameters()}
-        return P, L.decoder_weights(P, self.dims.attention_kind)
+        return P, L.decoder_weights(P, self.dims.attention_kind, single=self.single)
 
     # -- reference surface -----------------------------------------------------------------
     def forward(self, memory, embeddings, decoder_inputs, memory_lengths, bert_lengths, channels_last=False):
@@ -213,7 +218,7 @@ class Decoder(nn.Module):
         Returns mel [B,n_mel,T'], gate [B,T',1], align, align_bert, INFER_FLAG."""
         P, W = self._weights()
         with torch.no_grad():
-            dp, steps, stop = ops.decoder_infer(W, self.dims, memory.contiguous(), embeddings.contiguous(),
+            dp, steps, stop = ops.decoder_infer(W, self.dims, memory.contiguous(), None if embeddings is None else embeddings.contiguous(),
                                                 max_steps=int(self.max_decoder_steps), gate_threshold=float(self.gate_threshold),
                                                 prenet_dropout=self.prenet_dropout, seed=self._next_seed())
         stop = stop.cpu()
@@ -304,10 +309,52 @@ class BERT_Tacotron2(nn.Module):
 
 
 class Tacotron2(nn.Module):
-    """Single-stream classic API that the reference's stale callers import (GTA.py:6, inference.py:302;
-    SURVEY.md F4).  The reference itself has no such class; it is scheduled after the dual-stream
-    path (DESIGN.md, 'next')."""
+    """Classic single-stream Tacotron2 with the API the reference's stale callers expect (GTA.py:6,21,57-59,
+    inference.py:302,334, streamlitNews.py:8): forward((text, in_len, mel, max_len, out_len)) ->
+    [mel, mel_postnet, gate, align]; inference(ids) -> [mel, mel_postnet, gate, align].  The reference itself
+    has no such class (model.py exports only BERT_Tacotron2), so this class has no reference oracle: its parity
+    is pinned by the CPU restatement only (oracle.forward_single).  Same kernels, n_streams = 1; the attention
+    type follows hparams.attention (SMA by default in this repo's hparams, LSA in the classic recipe)."""
 
     def __init__(self, hparams):
         super().__init__()
-        raise NotImplementedError("single-stream Tacotron2 (GTA.py surface) is not built yet; use BERT_Tacotron2")
+        hp = hparams
+        self.mask_padding, self.fp16_run = hp.mask_padding, hp.fp16_run
+        self.n_mel_channels, self.n_frames_per_step = hp.n_mel_channels, hp.n_frames_per_step
+        self.embedding = nn.Embedding(hp.n_symbols, hp.symbols_embedding_dim)
+        val = sqrt(3.0) * sqrt(2.0 / (hp.n_symbols + hp.symbols_embedding_dim))
+        self.embedding.weight.data.uniform_(-val, val)
+        self.encoder = Encoder(hp)
+        self.decoder = Decoder(hp, single=True)
+        self.postnet = Postnet(hp)
+
+    def parse_batch(self, batch):
+        text, il, mel, gate, ol = batch
+        text, il = to_gpu(text).long(), to_gpu(il).long()
+        max_len = int(torch.max(il).item())
+        mel, gate, ol = to_gpu(mel).float(), to_gpu(gate).float(), to_gpu(ol).long()
+        return ((text, il, mel, max_len, ol), (mel, gate))
+
+    def forward(self, inputs):
+        text, tl, mels, _, ol = inputs
+        tl, ol = tl.data, ol.data
+        seed = _next_seed(self)
+        memory = self.encoder.forward_btc(blocks.embedding(text, self.embedding.weight), tl, L.SITE["ENC0"], seed)
+        mel_btc, gate, al, _ = self.decoder(memory, None, mels, tl, None, channels_last=True)
+        post_btc = self.postnet.forward_btc(mel_btc, seed)
+        use_mask = self.mask_padding and ol is not None
+        mel = _FinalizeFn.apply(mel_btc, ol if use_mask else None, 0.0)
+        post = _FinalizeFn.apply(post_btc, ol if use_mask else None, 0.0)
+        if use_mask:
+            gate = gate.clone()
+            ops.mask_bt_(gate.data, ol, 1e3)
+            ops.mask_btc_(mel_btc.data, ol, 0.0)
+        return [mel, post, gate, al]
+
+    def inference(self, inputs):
+        seed = _next_seed(self)
+        memory = self.encoder.forward_btc(blocks.embedding(inputs, self.embedding.weight), None, L.SITE["ENC0"], seed)
+        mel_btc, gate, al, _, flag = self.decoder.inference(memory, None, channels_last=True)
+        mel_btc = mel_btc.contiguous()
+        post_btc = self.postnet.forward_btc(mel_btc, seed)
+        return [ops.finalize_bct(mel_btc, None, 0.0), ops.finalize_bct(post_btc, None, 0.0), gate, al]

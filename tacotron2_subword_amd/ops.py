@@ -66,7 +66,7 @@ def decoder_forward(W: L.DecoderWeights, dims: L.Dims, memory, memory_sub, mem_l
                     training: bool, prenet_dropout: bool, seed: int, keep=None) -> DecoderPass:
     """Teacher-forced decoder (Decoder.forward, model.py:392-428).  mels: [B,n_mel,T]."""
     B, Tin, _ = memory.shape
-    Tsub, T = memory_sub.shape[1], mels.shape[2]
+    Tsub, T = (1 if memory_sub is None else memory_sub.shape[1]), mels.shape[2]     # single-stream: no second memory
     dp = DecoderPass(dims, B, T, Tin, Tsub, memory.device)
     ml, sl = _i32(mem_lengths), _i32(sub_lengths)
     a = L.DecoderFwdArgs(B, T, Tin, Tsub, L.ptr(memory), L.ptr(memory_sub), L.ptr(ml), L.ptr(sl), L.ptr(mels),
@@ -81,13 +81,14 @@ def decoder_backward(W: L.DecoderWeights, P: dict, dims: L.Dims, dp: DecoderPass
                      training: bool, prenet_dropout: bool, seed: int, d_align=None, d_align_sub=None, prefix="decoder."):
     """Backward of decoder_forward.  P: the (reference-keyed) weight dict, used for gradient shapes.
     Returns (grads dict keyed like P, d_memory, d_memory_sub)."""
+    single = dims.n_streams == 1
     dev = memory.device
-    G = {prefix + k: torch.empty_like(P[prefix + k]) for k in L.DECODER_PARAM_KEYS_SMA}
-    GS = L.decoder_grads(G, prefix)
+    G = {prefix + k: torch.empty_like(P[prefix + k]) for k in L.decoder_param_keys(L.ATTN_SMA, single)}
+    GS = L.decoder_grads(G, prefix, single)
     bl = L.decoder_bwd_layout(dims, dp.B, dp.T, dp.Tin, dp.Tsub)
     bws = torch.empty(bl.total_floats, dtype=torch.float32, device=dev)
     d_mem = torch.empty_like(memory)
-    d_mem_sub = torch.empty_like(memory_sub)
+    d_mem_sub = None if single else torch.empty_like(memory_sub)
     a = L.DecoderBwdArgs(dp.B, dp.T, dp.Tin, dp.Tsub, L.ptr(memory), L.ptr(memory_sub), L.ptr(dp.align), L.ptr(dp.align_sub),
                          L.ptr(d_mel), L.ptr(d_gate), L.ptr(d_align), L.ptr(d_align_sub), L.ptr(d_mem), L.ptr(d_mem_sub),
                          L.ptr(dp.ws), L.ptr(bws), int(training), int(prenet_dropout), seed)
@@ -100,7 +101,7 @@ def decoder_infer(W: L.DecoderWeights, dims: L.Dims, memory, memory_sub, *, max_
     """Autoregressive decode (Decoder.inference, model.py:430-492) for any B.
     Returns (DecoderPass sized for max_steps, steps_run, stop_index[B] (int32, -1 = never stopped))."""
     B, Tin, _ = memory.shape
-    Tsub = memory_sub.shape[1]
+    Tsub = 1 if memory_sub is None else memory_sub.shape[1]
     dp = DecoderPass(dims, B, max_steps, Tin, Tsub, memory.device)
     stop = torch.empty(B, dtype=torch.int32, device=memory.device)
     done = torch.empty(1, dtype=torch.int32, device=memory.device)
