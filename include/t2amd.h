@@ -129,7 +129,7 @@ int t2_decoder_forward(const t2_dims* dims, const t2_decoder_weights* w, const t
 /* Backward of t2_decoder_forward (the autograd graph PyTorch builds for Decoder.forward in the
  * reference).  Gradients are written (not accumulated) into `g`, which has the shapes of the
  * weights; d_memory / d_memory_sub receive the gradient wrt the encoder memories.
- * SMA only in this version (T2_ATTN_LSA returns an error). */
+ * Both attention kinds; for LSA the location-layer gradient pointers of t2_attention_grads must be set. */
 typedef struct t2_lstm_grads { float *w_ih, *w_hh, *b_ih, *b_hh; } t2_lstm_grads;
 typedef struct t2_attention_grads { float *wq, *wm, *v, *loc_conv, *loc_dense; } t2_attention_grads;
 typedef struct t2_decoder_grads {
@@ -142,6 +142,7 @@ typedef struct t2_decoder_grads {
 typedef struct t2_decoder_bwd_layout {
     size_t total_floats;
     size_t ddout, ddin, dgd, dga, dgas, dctx, dctxs, dq, dqs, dv, dvs, dpm, dpms, carry, carrys;
+    size_t carryc, carrycs, dlconv, dlconvs, dldense, dldenses;   /* LSA only (zero-sized for SMA) */
     size_t dcd, dca, dcas, partd, parta, dp2, dp2s, dp1, dmel_t, dgate_t, dg16a, dg16d, colsum_ws, gemm_ws, gemm_ws_floats;
 } t2_decoder_bwd_layout;
 int t2_decoder_bwd_layout_query(const t2_dims* dims, int B, int T, int Tin, int Tsub, t2_decoder_bwd_layout* out);

@@ -86,7 +86,7 @@ class DecoderGrads(C.Structure):
 
 
 _BWD_LAYOUT_FIELDS = ["total_floats", "ddout", "ddin", "dgd", "dga", "dgas", "dctx", "dctxs", "dq", "dqs", "dv", "dvs",
-                      "dpm", "dpms", "carry", "carrys", "dcd", "dca", "dcas", "partd", "parta", "dp2", "dp2s", "dp1",
+                      "dpm", "dpms", "carry", "carrys", "carryc", "carrycs", "dlconv", "dlconvs", "dldense", "dldenses", "dcd", "dca", "dcas", "partd", "parta", "dp2", "dp2s", "dp1",
                       "dmel_t", "dgate_t", "dg16a", "dg16d", "colsum_ws", "gemm_ws", "gemm_ws_floats"]
 
 
@@ -277,12 +277,18 @@ def decoder_param_keys(kind: int, single: bool = False):
     return [k for k in keys if "_bert" not in k] if single else keys
 
 
-def decoder_grads(G: dict, prefix: str = "decoder.", single: bool = False) -> DecoderGrads:
-    """Pack pointers of gradient buffers keyed like the weights (SMA parameter set)."""
+def decoder_grads(G: dict, prefix: str = "decoder.", single: bool = False, kind: int = ATTN_SMA) -> DecoderGrads:
+    """Pack pointers of gradient buffers keyed like the weights."""
     p = lambda k: ptr(G[prefix + k])
     lstm = lambda n: LstmGrads(p(n + ".weight_ih"), p(n + ".weight_hh"), p(n + ".bias_ih"), p(n + ".bias_hh"))
-    attn = lambda n: AttentionGrads(p(n + ".query_layer.linear_layer.weight"), p(n + ".memory_layer.linear_layer.weight"),
-                                    p(n + ".v.weight"), None, None)
+
+    def attn(n):
+        if kind == ATTN_SMA:
+            return AttentionGrads(p(n + ".query_layer.linear_layer.weight"), p(n + ".memory_layer.linear_layer.weight"),
+                                  p(n + ".v.weight"), None, None)
+        return AttentionGrads(p(n + ".query_layer.linear_layer.weight"), p(n + ".memory_layer.linear_layer.weight"),
+                              p(n + ".v.linear_layer.weight"), p(n + ".location_layer.location_conv.conv.weight"),
+                              p(n + ".location_layer.location_dense.linear_layer.weight"))
     none_l, none_a = LstmGrads(None, None, None, None), AttentionGrads(None, None, None, None, None)
     return DecoderGrads(p("prenet.layers.0.linear_layer.weight"), p("prenet.layers.1.linear_layer.weight"),
                         None if single else p("prenet_bert.layers.0.linear_layer.weight"),

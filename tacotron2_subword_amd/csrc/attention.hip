@@ -349,6 +349,279 @@ __global__ __launch_bounds__(NTB) void attention_step_bwd_kernel(AttnBwdDesc d) 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Backward of one LocationSensitiveAttention step (reverse time), one workgroup per (b, stream).
+//   forward:  loc_jf = sum_{c,k} Wc[f][c][k] wcat[c][j+k-pad]      wcat = [w_{t-1} ; cum_{t-1}]
+//             u_ja = tanh(q_a + sum_f Wd[a][f] loc_jf + pm_ja) ; e_j = v . u_j ; w = softmax(e)
+//             cum_t = cum_{t-1} + w ; ctx = w . memory
+//   backward: g_j  = dctx . memory_j + dalign_j + carry_w_j + carry_cum_j       total gradient on w_t[j]
+//             de_j = w_j (g_j - sum_k w_k g_k)                                   softmax
+//             dpre_ja = de_j v_a (1 - u_ja^2) ; dq_a = sum_j dpre_ja ; dv_a += sum_j de_j u_ja ; dpm_ja += dpre_ja
+//             dWd[a][f] += sum_j dpre_ja loc_jf ; dloc_jf = sum_a dpre_ja Wd[a][f]
+//             dWc[f][c][k] += sum_j dloc_jf wcat[c][j+k-pad]
+//             dwcat[c][i] = sum_{f,k} Wc[f][c][k] dloc_{i-k+pad, f}
+//             carry_w <- dwcat[0] (gradient on w_{t-1}) ; carry_cum <- carry_cum + dwcat[1] (gradient on cum_{t-1})
+// Positions are processed 32 at a time (16 lanes each); the per-chunk dpre tile goes through LDS
+// for the two location-layer contractions.  Fixed summation orders everywhere (no atomics).
+// ---------------------------------------------------------------------------------------------
+constexpr int NPG = NTB / 16;     // positions per chunk
+constexpr int NQ = 4;             // f-groups of the dwcat contraction
+
+struct LsaBwdSmem { int dctx, q, vs, g, w, de, wpad, convw, dense, dlocP, X, dpreS, loc, red2, tmp, total; };
+__host__ __device__ inline LsaBwdSmem lsa_bwd_smem(int Tin, int A, int E, int F, int Kc) {
+    LsaBwdSmem m; int o = 0;
+    const int Tp = (Tin + 3) & ~3, Tw = Tin + Kc - 1;
+    auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+    m.dctx = take(E); m.q = take(A); m.vs = take(A); m.g = take(Tp); m.w = take(Tp); m.de = take(Tp);
+    m.wpad = take(2 * Tw); m.convw = take(F * 2 * Kc); m.dense = take(A * (F + 1));
+    m.dlocP = take(Tw * (F + 1));
+    const int xs = NPG * (A + 4) + Tin * (F + 1), rs = 2 * NPG * A;     // dpre tile + loc, later reused for the dq/dv partials
+    m.X = take(xs > rs ? xs : rs); m.dpreS = m.X; m.loc = m.X + NPG * (A + 4);
+    m.red2 = take(NTB / 64 + 4); m.tmp = take(NQ * 2 * Tin);
+    m.total = o;
+    return m;
+}
+
+__device__ __forceinline__ float block_sum_b(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < NTB / 64; ++i) r += red[i];
+    return r;
+}
+
+template <int MAXI>
+__global__ __launch_bounds__(NTB) void attention_lsa_step_bwd_kernel(AttnBwdDesc d) {
+    const AttnBwdStream& st = d.st[blockIdx.y];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int Tin = st.Tin, A = d.A, E = d.E, F = d.F, Kc = d.Kc;
+    const int pad = (Kc - 1) / 2, Tw = Tin + Kc - 1, F1 = F + 1, AS = A + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const LsaBwdSmem m = lsa_bwd_smem(Tin, A, E, F, Kc);
+    float* dctx = smem + m.dctx; float* q = smem + m.q; float* vs = smem + m.vs;
+    float* g = smem + m.g; float* wS = smem + m.w; float* de = smem + m.de;
+    float* wpad = smem + m.wpad; float* convw = smem + m.convw; float* dense = smem + m.dense;
+    float* dlocP = smem + m.dlocP; float* dpreS = smem + m.dpreS; float* loc = smem + m.loc;
+    float* red2 = smem + m.red2; float* tmp = smem + m.tmp;
+
+    // ---- stage: total ctx gradient, query, v, weights of this step, location-layer weights, padded conv input
+    for (int c = tid; c < E; c += NTB) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) if (st.dctx[i]) v += st.dctx[i][(long)b * st.lddctx[i] + c];
+        if (st.part && !d.first) {
+            const float* p = st.part + (long)b * st.ldpart + st.part_col + c;
+            float pv[8];
+#pragma unroll
+            for (int z = 0; z < 8; ++z) pv[z] = z < st.nparts ? p[(long)z * st.part_stride] : 0.f;
+            float acc = 0.f;
+#pragma unroll
+            for (int z = 0; z < 8; ++z) acc += pv[z];
+            v += acc;
+        }
+        dctx[c] = v;
+        st.dctx_out[(long)b * st.lddctx_out + c] = v;
+    }
+    for (int a = tid; a < A; a += NTB) { q[a] = st.q[(long)b * st.ldq + a]; vs[a] = st.v[a]; }
+    for (int j = tid; j < Tin; j += NTB) wS[j] = st.w[(long)b * st.ldw + j];
+    for (int i = tid; i < F * 2 * Kc; i += NTB) convw[i] = st.loc_conv[i];
+    for (int i = tid; i < A * F; i += NTB) dense[(i / F) * F1 + (i % F)] = st.loc_dense[i];
+    for (int i = tid; i < 2 * Tw; i += NTB) {
+        const int c = i / Tw, j = i % Tw - pad;
+        float v = 0.f;
+        if (j >= 0 && j < Tin) v = c == 0 ? (st.a_prev ? st.a_prev[(long)b * st.lda_prev + j] : 0.f)
+                                          : (st.wcum_prev ? st.wcum_prev[(long)b * st.ldwcum_prev + j] : 0.f);
+        wpad[i] = v;
+    }
+    for (int i = tid; i < Tw * F1; i += NTB) dlocP[i] = 0.f;          // rows [pad, pad+Tin) are overwritten below
+    __syncthreads();
+
+    // ---- g_j = dctx . memory_j (+ external and carried gradients): one wave per position, 4 in flight
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        constexpr int NWV = NTB / 64, U = 4;
+        for (int j0 = wave; j0 < Tin; j0 += NWV * U) {
+            float sum[U] = {0.f, 0.f, 0.f, 0.f};
+            for (int c = lane * 4; c < E; c += 256) {
+                const f32x4 dc = *reinterpret_cast<const f32x4*>(dctx + c);
+                f32x4 mv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int j = min(j0 + u * NWV, Tin - 1);
+                    mv[u] = *reinterpret_cast<const f32x4*>(st.memory + ((long)b * Tin + j) * E + c);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) sum[u] += mv[u][0] * dc[0] + mv[u][1] * dc[1] + mv[u][2] * dc[2] + mv[u][3] * dc[3];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u * NWV;
+                const float tot = wave_sum(sum[u]);
+                if (lane == 0 && j < Tin) {
+                    float gsum = tot;
+                    if (st.dalign) gsum += st.dalign[(long)b * st.lddalign + j];
+                    if (!d.first) gsum += st.carry[(long)b * Tin + j] + st.carry_cum[(long)b * Tin + j];
+                    g[j] = gsum;
+                }
+            }
+        }
+    }
+    // ---- location conv recomputed (same loop order as the forward kernel)
+    for (int i = tid; i < Tin * F; i += NTB) {
+        const int j = i / F, f = i % F;
+        float sum = 0.f;
+        for (int c = 0; c < 2; ++c) {
+            const float* w = convw + (f * 2 + c) * Kc;
+            const float* x = wpad + c * Tw + j;
+            for (int k = 0; k < Kc; ++k) sum += w[k] * x[k];
+        }
+        loc[j * F1 + f] = sum;
+    }
+    __syncthreads();
+    // ---- softmax backward
+    {
+        float part = 0.f;
+        for (int j = tid; j < Tin; j += NTB) part += wS[j] * g[j];
+        const float sdot = block_sum_b(part, red2);
+        for (int j = tid; j < Tin; j += NTB) de[j] = wS[j] * (g[j] - sdot);
+    }
+    __syncthreads();
+
+    // ---- energies backward + location-layer contractions, NPG positions per chunk
+    const int gid = tid >> 4, sub = tid & 15;
+    float dq[MAXI][4], dv[MAXI][4], dd[4 * MAXI];
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { dq[i][c] = 0.f; dv[i][c] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 4 * MAXI; ++k) dd[k] = 0.f;
+    for (int j0 = 0; j0 < Tin; j0 += NPG) {
+        const int j = j0 + gid;
+        const bool valid = j < Tin;
+        const int jc = valid ? j : Tin - 1;
+        const float dej = valid ? de[jc] : 0.f;
+        const float* pmr = st.pm + ((long)b * Tin + jc) * A;
+        float* dpr = st.dpm_acc + ((long)b * Tin + jc) * A;
+        const float* lr = loc + jc * F1;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int a = sub * 4 + 64 * i;
+            if (a < A) {
+                const f32x4 pv = *reinterpret_cast<const f32x4*>(pmr + a);
+                f32x4 acc = d.first ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(dpr + a);
+                float pa[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int f = 0; f < F; ++f) {
+                    const float lv = lr[f];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) pa[c] += dense[(a + c) * F1 + f] * lv;
+                }
+                f32x4 dp;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float u = tanhf(q[a + c] + pa[c] + pv[c]);
+                    const float dpre = dej * vs[a + c] * (1.0f - u * u);
+                    dq[i][c] += dpre;
+                    dv[i][c] += dej * u;
+                    acc[c] += dpre;
+                    dp[c] = dpre;
+                }
+                if (valid) *reinterpret_cast<f32x4*>(dpr + a) = acc;
+                *reinterpret_cast<f32x4*>(dpreS + gid * AS + a) = dp;
+            }
+        }
+        __syncthreads();
+        const int nj = min(NPG, Tin - j0);
+        // dloc rows of this chunk
+        for (int it = tid; it < nj * F; it += NTB) {
+            const int jj = it / F, f = it % F;
+            const float* dr = dpreS + jj * AS;
+            float sum = 0.f;
+            for (int a = 0; a < A; ++a) sum += dr[a] * dense[a * F1 + f];
+            dlocP[(j0 + jj + pad) * F1 + f] = sum;
+        }
+        // d(location_dense): thread-owned outputs o = tid + k*NTB  ->  (a, f) = (o / F, o % F)
+#pragma unroll
+        for (int k = 0; k < 4 * MAXI; ++k) {
+            const int o = tid + k * NTB;
+            if (o < A * F) {
+                const int a = o / F, f = o % F;
+                float sum = dd[k];
+                for (int jj = 0; jj < nj; ++jj) sum += dpreS[jj * AS + a] * loc[(j0 + jj) * F1 + f];
+                dd[k] = sum;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 4 * MAXI; ++k) {
+        const int o = tid + k * NTB;
+        if (o < A * F) {
+            float* p = st.ddense_acc + (long)b * A * F + o;
+            *p = (d.first ? 0.f : *p) + dd[k];
+        }
+    }
+    // dq / dv: reduce the NPG position groups (the dpre tile + loc region is free now)
+    {
+        float* rq = smem + m.X;
+        float* rv = rq + NPG * A;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int a = sub * 4 + 64 * i;
+            if (a < A) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { rq[gid * A + a + c] = dq[i][c]; rv[gid * A + a + c] = dv[i][c]; }
+            }
+        }
+        __syncthreads();
+        for (int a = tid; a < A; a += NTB) {
+            float sq = 0.f, sv = 0.f;
+            for (int k = 0; k < NPG; ++k) { sq += rq[k * A + a]; sv += rv[k * A + a]; }
+            st.dq_out[(long)b * st.lddq_out + a] = sq;
+            float* dvp = st.dv_acc + (long)b * A + a;
+            *dvp = (d.first ? 0.f : *dvp) + sv;
+        }
+    }
+    // d(location_conv)[f][c][k] += sum_j dloc_jf wcat[c][j+k-pad]
+    for (int it = tid; it < F * 2 * Kc; it += NTB) {
+        const int f = it / (2 * Kc), c = (it / Kc) % 2, k = it % Kc;
+        const float* x = wpad + c * Tw + k;
+        float sum = 0.f;
+        for (int j = 0; j < Tin; ++j) sum += dlocP[(j + pad) * F1 + f] * x[j];
+        float* p = st.dconv_acc + (long)b * F * 2 * Kc + it;
+        *p = (d.first ? 0.f : *p) + sum;
+    }
+    // gradient on the conv input: dwcat[c][i] = sum_{f,k} Wc[f][c][k] dloc[i-k+pad][f]   (zero-padded rows)
+    if (st.a_prev) {
+        for (int it = tid; it < NQ * 2 * Tin; it += NTB) {
+            const int fq = it / (2 * Tin), c = (it / Tin) % 2, i = it % Tin;
+            float sum = 0.f;
+            for (int f = fq; f < F; f += NQ) {
+                const float* w = convw + (f * 2 + c) * Kc;
+                const float* dl = dlocP + (i + 2 * pad) * F1 + f;
+                for (int k = 0; k < Kc; ++k) sum += w[k] * dl[-k * F1];
+            }
+            tmp[it] = sum;
+        }
+        __syncthreads();
+        for (int it = tid; it < 2 * Tin; it += NTB) {
+            float sum = 0.f;
+#pragma unroll
+            for (int fq = 0; fq < NQ; ++fq) sum += tmp[fq * 2 * Tin + it];
+            const int c = it / Tin, i = it % Tin;
+            if (c == 0) st.carry[(long)b * Tin + i] = sum;
+            else {
+                float* p = st.carry_cum + (long)b * Tin + i;
+                *p = (d.first ? 0.f : *p) + sum;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 size_t attention_fwd_smem(const AttnStepDesc& d) {
@@ -380,11 +653,29 @@ int attention_step_fwd(const AttnStepDesc& d, hipStream_t s) {
 }
 
 
+template <int MAXI>
+static int launch_lsa_bwd(const AttnBwdDesc& d, size_t smem, hipStream_t s) {
+    if (smem > 64 * 1024)
+        T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_lsa_step_bwd_kernel<MAXI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(attention_lsa_step_bwd_kernel<MAXI>, dim3(d.B, d.nstreams), dim3(NTB), smem, s, d);
+    T2_LAUNCH_CHECK();
+    return 0;
+}
+
 int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s) {
     T2_REQUIRE(d.nstreams >= 1 && d.nstreams <= 2, "attention_bwd: nstreams=%d", d.nstreams);
     T2_REQUIRE(d.A % 4 == 0 && d.A <= 256 && d.E % 4 == 0, "attention_bwd: A=%d E=%d unsupported", d.A, d.E);
     int Tmax = 0;
     for (int i = 0; i < d.nstreams; ++i) Tmax = d.st[i].Tin > Tmax ? d.st[i].Tin : Tmax;
+    if (d.kind == 1) {
+        T2_REQUIRE(d.Kc % 2 == 1 && d.F >= 1 && d.F <= 32, "attention_bwd (LSA): location layer F=%d (<= 32) Kc=%d (odd) unsupported", d.F, d.Kc);
+        for (int i = 0; i < d.nstreams; ++i)
+            T2_REQUIRE(d.st[i].w && d.st[i].carry_cum && d.st[i].dconv_acc && d.st[i].ddense_acc && d.st[i].loc_conv && d.st[i].loc_dense,
+                       "attention_bwd (LSA): missing buffers");
+        const size_t smem = (size_t)lsa_bwd_smem(Tmax, d.A, d.E, d.F, d.Kc).total * sizeof(float);
+        T2_REQUIRE(smem <= 160 * 1024, "attention_bwd (LSA): T_in=%d too long for LDS (%zu bytes > 160 KiB)", Tmax, smem);
+        return d.A <= 128 ? launch_lsa_bwd<2>(d, smem, s) : launch_lsa_bwd<4>(d, smem, s);
+    }
     const int Tp = (Tmax + 3) & ~3;
     const size_t smem = ((size_t)d.E + 2 * d.A + (Tp + 4) + 2 * Tp + 2 * (NTB / 16) * (size_t)d.A) * sizeof(float);
     T2_REQUIRE(smem <= 160 * 1024, "attention_bwd: T_in too long for LDS (%zu bytes)", smem);

@@ -330,6 +330,10 @@ void bwd_layout_of(const t2_dims& d, const Sizes& z, t2_decoder_bwd_layout* L) {
     L->dv = take((size_t)z.B * z.A); L->dvs = take((size_t)z.B * z.A);
     L->dpm = take((size_t)z.B * z.Tin * z.A); L->dpms = take((size_t)z.B * z.Tsub * z.A);
     L->carry = take((size_t)z.B * z.Tin); L->carrys = take((size_t)z.B * z.Tsub);
+    const bool lsa = d.attention_kind == T2_ATTN_LSA;          // LSA: cumulative-weight carry + per-item location-layer gradients
+    const size_t ncv = lsa ? (size_t)z.B * d.loc_filters * 2 * d.loc_kernel : 0, nds = lsa ? (size_t)z.B * z.A * d.loc_filters : 0;
+    L->carryc = take(lsa ? (size_t)z.B * z.Tin : 0); L->carrycs = take(lsa ? (size_t)z.B * z.Tsub : 0);
+    L->dlconv = take(ncv); L->dlconvs = take(ncv); L->dldense = take(nds); L->dldenses = take(nds);
     L->dcd = take((size_t)z.B * z.Hd); L->dca = take((size_t)z.B * z.Ha); L->dcas = take((size_t)z.B * z.Ha);
     L->partd = take((size_t)ksd * z.B * z.Hd);
     L->parta = take((size_t)2 * ksa * z.B * (z.E + z.Ha));
@@ -410,6 +414,7 @@ int att_bwd_step(const Bwd& c, int t) {
     // 1. attention backward (needs dctx(t) incl. the recurrent partials of step t+1)
     AttnBwdDesc ab{};
     ab.nstreams = z.NS; ab.B = z.B; ab.A = z.A; ab.E = z.E; ab.first = first;
+    ab.kind = c.d.attention_kind; ab.F = c.d.loc_filters; ab.Kc = c.d.loc_kernel;
     for (int s = 0; s < z.NS; ++s) {
         AttnBwdStream& st = ab.st[s];
         const int Tin = s ? z.Tsub : z.Tin;
@@ -422,10 +427,21 @@ int att_bwd_step(const Bwd& c, int t) {
         if (dal) { st.dalign = dal + (long)t * Tin; st.lddalign = (long)z.T * Tin; }
         st.q = c.W(s ? c.L.qss : c.L.qs) + c.R(t) * z.A; st.ldq = z.A;
         st.pm = c.W(s ? c.L.pms : c.L.pm); st.memory = s ? c.a.memory_sub : c.a.memory;
-        st.p = c.W(s ? c.L.psels : c.L.psel) + (long)t * Tin; st.ldp = (long)z.T * Tin;
         const float* al = s ? c.a.align_sub : c.a.align;
-        if (t > 0) { st.a_prev = al + (long)(t - 1) * Tin; st.lda_prev = (long)z.T * Tin; }
-        st.v = s ? c.w.attn_sub.v : c.w.attn.v;
+        const long ldA = (long)z.T * Tin;
+        if (t > 0) { st.a_prev = al + (long)(t - 1) * Tin; st.lda_prev = ldA; }
+        const t2_attention_weights& aw = s ? c.w.attn_sub : c.w.attn;
+        st.v = aw.v;
+        if (ab.kind == T2_ATTN_SMA) {
+            st.p = c.W(s ? c.L.psels : c.L.psel) + (long)t * Tin; st.ldp = ldA;
+        } else {
+            st.w = al + (long)t * Tin; st.ldw = ldA;
+            if (t > 0) { st.wcum_prev = c.W(s ? c.L.wcums : c.L.wcum) + (long)(t - 1) * Tin; st.ldwcum_prev = ldA; }
+            st.loc_conv = aw.loc_conv; st.loc_dense = aw.loc_dense;
+            st.carry_cum = c.S(s ? c.BL.carrycs : c.BL.carryc);
+            st.dconv_acc = c.S(s ? c.BL.dlconvs : c.BL.dlconv);
+            st.ddense_acc = c.S(s ? c.BL.dldenses : c.BL.dldense);
+        }
         st.carry = c.S(s ? c.BL.carrys : c.BL.carry);
         st.dctx_out = c.S(s ? c.BL.dctxs : c.BL.dctx) + c.R(t) * z.E; st.lddctx_out = z.E;
         st.dq_out = c.S(s ? c.BL.dqs : c.BL.dq) + c.R(t) * z.A; st.lddq_out = z.A;
@@ -549,7 +565,6 @@ int t2_decoder_backward(const t2_dims* dims, const t2_decoder_weights* w, const 
                         const t2_decoder_bwd_args* a, void* stream) {
     T2_REQUIRE(dims && w && g && a, "null argument");
     T2_TRY(check_dims(*dims));
-    T2_REQUIRE(dims->attention_kind == T2_ATTN_SMA, "t2_decoder_backward: only StepwiseMonotonicAttention has a backward kernel in this version");
     Bwd c{*dims, *w, *g, *a, sizes_of(*dims, a->B, a->T, a->Tin, a->Tsub), {}, {}, (hipStream_t)stream};
     layout_of(*dims, c.z, &c.L);
     bwd_layout_of(*dims, c.z, &c.BL);
@@ -624,6 +639,11 @@ int t2_decoder_backward(const t2_dims* dims, const t2_decoder_weights* w, const 
         // attention parameters
         T2_TRY(gemm(matmul_tn(c, c.S(s ? BL.dqs : BL.dq), z.A, DIN + hoff, z.WD, ag.wq, z.Ha, z.A, z.Ha, BT), c.s));
         T2_TRY(batch_sum(c.S(s ? BL.dvs : BL.dv), z.B, z.A, ag.v, c.s));
+        if (dims->attention_kind == T2_ATTN_LSA) {
+            T2_REQUIRE(ag.loc_conv && ag.loc_dense, "t2_decoder_backward: LSA needs loc_conv / loc_dense gradient buffers");
+            T2_TRY(batch_sum(c.S(s ? BL.dlconvs : BL.dlconv), z.B, dims->loc_filters * 2 * dims->loc_kernel, ag.loc_conv, c.s));
+            T2_TRY(batch_sum(c.S(s ? BL.dldenses : BL.dldense), z.B, z.A * dims->loc_filters, ag.loc_dense, c.s));
+        }
         const float* mem = s ? a->memory_sub : a->memory;
         float* dmem = s ? a->d_memory_sub : a->d_memory;
         const float* DPM = c.S(s ? BL.dpms : BL.dpm);

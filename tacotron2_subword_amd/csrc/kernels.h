@@ -120,7 +120,7 @@ struct AttnStepDesc {
 };
 int attention_step_fwd(const AttnStepDesc& d, hipStream_t s);
 
-// Backward of one SMA attention step (reverse time).
+// Backward of one attention step (reverse time): SMA (kind 0) or LSA (kind 1).
 struct AttnBwdStream {
     const float* dctx[3]; long lddctx[3];  // direct gradient sources on ctx(t) [B,E] (nullable entries)
     const float* part; int nparts; long part_stride; long ldpart; int part_col;   // recurrent partials (ctx columns)
@@ -136,8 +136,14 @@ struct AttnBwdStream {
     float* dv_acc;                         // [B,A] accumulated over steps
     float* dpm_acc;                        // [B,Tin,A] accumulated over steps
     int Tin;
+    // LSA only
+    const float* w; long ldw;              // saved attention weights of step t [B,Tin] (a_prev = weights of step t-1)
+    const float* wcum_prev; long ldwcum_prev;   // cumulative weights before step t (null at t=0)
+    const float* loc_conv; const float* loc_dense;   // [F,2,Kc], [A,F]
+    float* carry_cum;                      // [B,Tin] gradient on the cumulative weights (in/out); `carry` holds the w_{t-1} part
+    float* dconv_acc; float* ddense_acc;   // [B,F*2*Kc], [B,A*F] per-item weight gradients accumulated over steps
 };
-struct AttnBwdDesc { AttnBwdStream st[2]; int nstreams; int B, A, E; int first; };
+struct AttnBwdDesc { AttnBwdStream st[2]; int nstreams; int B, A, E; int first; int kind, F, Kc; };
 int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s);
 
 // ------------------------------------------------------------------ conv + BN stacks, embedding (conv.hip)

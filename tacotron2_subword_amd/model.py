@@ -206,9 +206,6 @@ class Decoder(nn.Module):
         gate [B,T], align [B,T,Tin], align_bert [B,T,Tsub]."""
         cfg = dict(decoder=self, keys=self._param_keys(), training=self.training, prenet_dropout=self.prenet_dropout,
                    seed=self._next_seed())
-        if self.dims.attention_kind != L.ATTN_SMA and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("training with LocationSensitiveAttention: the LSA backward kernel is not built yet "
-                                      "(forward / inference are); use torch.no_grad() or StepwiseMonotonicAttention")
         mel, gate, al, alb = _DecoderFn.apply(memory, embeddings, decoder_inputs, memory_lengths, bert_lengths, cfg,
                                               *self._params())
         return (mel if channels_last else mel.transpose(1, 2)), gate, al, alb

@@ -83,8 +83,8 @@ def decoder_backward(W: L.DecoderWeights, P: dict, dims: L.Dims, dp: DecoderPass
     Returns (grads dict keyed like P, d_memory, d_memory_sub)."""
     single = dims.n_streams == 1
     dev = memory.device
-    G = {prefix + k: torch.empty_like(P[prefix + k]) for k in L.decoder_param_keys(L.ATTN_SMA, single)}
-    GS = L.decoder_grads(G, prefix, single)
+    G = {prefix + k: torch.empty_like(P[prefix + k]) for k in L.decoder_param_keys(dims.attention_kind, single)}
+    GS = L.decoder_grads(G, prefix, single, dims.attention_kind)
     bl = L.decoder_bwd_layout(dims, dp.B, dp.T, dp.Tin, dp.Tsub)
     bws = torch.empty(bl.total_floats, dtype=torch.float32, device=dev)
     d_mem = torch.empty_like(memory)

@@ -1,5 +1,5 @@
 """GPU parity of the hand-written decoder backward (BPTT through both attention LSTMs, the
-stepwise-monotonic attention recurrence, the decoder LSTM, prenets and projections) against
+stepwise-monotonic / location-sensitive attention recurrence, the decoder LSTM, prenets and projections) against
 torch.autograd run on the CPU oracle — the reference has no backward source of its own
 (it is autograd of model.py:392-428), so this is the oracle for gradients."""
 import numpy as np
@@ -9,7 +9,7 @@ import torch
 from oracle import recipe
 from oracle import tacotron2_oracle as O
 
-from helpers import SMA, hp_for, maxabs, oracle_memories, tiny_hp, to_dev
+from helpers import LSA, SMA, hp_for, maxabs, oracle_memories, tiny_hp, to_dev
 
 pytestmark = pytest.mark.gpu
 RTOL = 3e-4          # max-abs error relative to the largest reference entry of each gradient tensor
@@ -38,16 +38,20 @@ def hip_rnd(ops, L, hp, seed, B, T, Tin, Tsub):
                 sma_noise_bert=ops.rng_normal(seed, S["NOISE_SUB"], B * T * Tsub).view(T, B, Tsub).cpu())
 
 
-@pytest.mark.parametrize("cfg", ["tiny_eval", "tiny_train", "tiny_b33", "default_train", "default_align"])
-def test_decoder_backward_vs_autograd(env, cfg):
+@pytest.mark.parametrize("cfg", ["tiny_eval", "tiny_train", "tiny_b33", "tiny_long", "default_train", "default_align"])
+@pytest.mark.parametrize("att", [SMA, LSA])
+def test_decoder_backward_vs_autograd(env, cfg, att):
     L, ops = env
-    training = cfg in ("tiny_train", "default_train", "default_align", "tiny_b33")
-    with_align = cfg in ("default_align", "tiny_b33")
-    if cfg.startswith("tiny"):
-        hp = tiny_hp(SMA)
+    training = cfg in ("tiny_train", "default_train", "default_align", "tiny_b33", "tiny_long")
+    with_align = cfg in ("default_align", "tiny_b33", "tiny_long")
+    if cfg == "tiny_long":                       # several 32-position chunks per attention step, ragged tails
+        hp = tiny_hp(att)
+        B, Tin, Tsub, T = 2, 70, 37, 6
+    elif cfg.startswith("tiny"):
+        hp = tiny_hp(att)
         B, Tin, Tsub, T = (33 if cfg == "tiny_b33" else 5), 11, 7, 9
     else:
-        hp = hp_for(SMA)
+        hp = hp_for(att)
         B, Tin, Tsub, T = 3, 13, 8, 12
     seed = 99173
     P = recipe.make_weights(hp, seed=5)
@@ -55,18 +59,28 @@ def test_decoder_backward_vs_autograd(env, cfg):
     mem, mem_sub = oracle_memories(P, hp, x)
     rnd = hip_rnd(ops, L, hp, seed, B, T, Tin, Tsub) if training else None
 
-    # ---- oracle: autograd
-    dec_keys = ["decoder." + k for k in L.DECODER_PARAM_KEYS_SMA]
-    Pg = {k: (v.clone().requires_grad_(True) if k in dec_keys else v) for k, v in P.items()}
-    mem_g, mem_sub_g = mem.clone().requires_grad_(True), mem_sub.clone().requires_grad_(True)
-    mel, gate, al, alb = O.decoder_forward(mem_g, mem_sub_g, x[3], x[1], x[2], Pg, hp, rnd)
+    # ---- oracle: autograd, in fp32 (the reference's arithmetic) and in fp64 (ground truth for the tolerance)
+    dec_keys = ["decoder." + k for k in L.decoder_param_keys(L.ATTN_SMA if att == SMA else L.ATTN_LSA)]
     g = torch.Generator().manual_seed(17)
-    R_mel, R_gate = torch.randn(mel.shape, generator=g), torch.randn(gate.shape, generator=g)
-    R_al, R_alb = torch.randn(al.shape, generator=g), torch.randn(alb.shape, generator=g)
-    loss = (mel * R_mel).sum() + (gate * R_gate).sum()
-    if with_align:
-        loss = loss + (al * R_al).sum() + (alb * R_alb).sum()
-    loss.backward()
+    R_mel, R_gate = torch.randn(B, hp["n_mel_channels"], T, generator=g), torch.randn(B, T, generator=g)
+    R_al, R_alb = torch.randn(B, T, Tin, generator=g), torch.randn(B, T, Tsub, generator=g)
+
+    def autograd(dt):
+        cv = lambda v: v.to(dt) if torch.is_tensor(v) and v.is_floating_point() else v
+        Pg = {k: (cv(v).clone().requires_grad_(True) if k in dec_keys else cv(v)) for k, v in P.items()}
+        r = None if rnd is None else {k: ([cv(a) for a in v] if isinstance(v, list) else cv(v)) for k, v in rnd.items()}
+        mem_g, mem_sub_g = cv(mem).clone().requires_grad_(True), cv(mem_sub).clone().requires_grad_(True)
+        mel, gate, al, alb = O.decoder_forward(mem_g, mem_sub_g, cv(x[3]), x[1], x[2], Pg, hp, r)
+        loss = (mel * cv(R_mel)).sum() + (gate * cv(R_gate)).sum()
+        if with_align:
+            loss = loss + (al * cv(R_al)).sum() + (alb * cv(R_alb)).sum()
+        loss.backward()
+        out = {k: Pg[k].grad for k in dec_keys}
+        out["d_memory"], out["d_memory_sub"] = mem_g.grad, mem_sub_g.grad
+        return mel.detach(), out
+
+    mel, g32 = autograd(torch.float32)
+    _, g64 = autograd(torch.float64)
 
     # ---- HIP
     dims = L.dims_from_hparams(hp)
@@ -84,10 +98,16 @@ def test_decoder_backward_vs_autograd(env, cfg):
     torch.cuda.synchronize()
 
     def rel(a, ref):
-        return maxabs(a, ref) / max(float(ref.abs().max()), 1e-6)
+        return maxabs(a.double(), ref.double()) / max(float(ref.abs().max()), 1e-6)
 
-    errs = {"d_memory": rel(dmem, mem_g.grad), "d_memory_sub": rel(dmems, mem_sub_g.grad)}
-    for k in dec_keys:
-        errs[k] = rel(G[k], Pg[k].grad)
-    bad = {k: v for k, v in errs.items() if not v < RTOL}
+    # The softmax / sigmoid-recurrence gradients cancel heavily, so even torch's fp32 autograd is only good to a few
+    # 1e-4 on the attention parameters: a tensor passes when it is within RTOL of the fp64 gradient, or no worse than
+    # 3x the fp32 oracle's own rounding error against fp64.
+    G = dict(G)
+    G["d_memory"], G["d_memory_sub"] = dmem, dmems
+    bad = {}
+    for k, ref in g64.items():
+        err, tol = rel(G[k], ref), max(RTOL, 3.0 * rel(g32[k], ref))
+        if not err < tol:
+            bad[k] = (err, tol)
     assert not bad, bad

@@ -40,10 +40,10 @@ def test_forward_eval_vs_golden(att, name):
         assert maxabs(v, g[k]) < TOL, k
 
 
-def test_backward_eval_mode_vs_oracle_autograd():
+@pytest.mark.parametrize("att", [SMA, LSA])
+def test_backward_eval_mode_vs_oracle_autograd(att):
     """Whole-model gradients (embeddings, encoders, converters, decoder, postnet) in eval mode (BN
     running statistics, no dropout, no noise): HIP backward of every block vs the oracle's autograd."""
-    att = SMA
     hp = hp_for(att)
     B, Tin, Tsub, T = 3, 13, 8, 12
     m, hps = build_model(att, train=False)
@@ -114,16 +114,17 @@ def test_training_step_runs_and_is_finite():
         assert moved == (not k.startswith("decoder.decoder_rnn_bert")), k
 
 
-def test_training_mode_full_model_vs_oracle():
+@pytest.mark.parametrize("att", [SMA, LSA])
+def test_training_mode_full_model_vs_oracle(att):
     """Training mode end to end: BN batch statistics, conv/LSTM-state/prenet dropout and SMA noise drawn
     by the HIP RNG (exported through the C ABI and replayed through the oracle), loss, every parameter
     gradient, and the BN running-statistics update."""
     from tacotron2_subword_amd import _lib as L
     from tacotron2_subword_amd import ops
     from tacotron2_subword_amd.loss_function import Tacotron2Loss
-    hp = hp_for(SMA)
+    hp = hp_for(att)
     B, Tin, Tsub, T = 3, 13, 8, 12
-    m, hps = build_model(SMA, train=True)
+    m, hps = build_model(att, train=True)
     m.decoder.prenet_dropout = True
     m._t2_calls, m.decoder._t2_calls = 0, 0
     seed = ((1234 * 1000003 + 1) * 64) & ((1 << 63) - 1)

@@ -52,8 +52,8 @@ def test_single_forward_eval_vs_oracle(att):
         assert maxabs(a, b) < TOL, k
 
 
-def test_single_backward_eval_vs_oracle_autograd():
-    att = SMA
+@pytest.mark.parametrize("att", [SMA, LSA])
+def test_single_backward_eval_vs_oracle_autograd(att):
     hp = hp_for(att)
     B, Tin, T = 3, 12, 10
     m = build_single(att)
