@@ -5,9 +5,13 @@ hparams (512-dim / 80-mel, dual-stream BERT_Tacotron2, StepwiseMonotonicAttentio
 LJSpeech-shaped batches (100 phones, 60 sub-word tokens, 400 frames) — BASELINE.json configs[1];
 with --gpus N: configs[2] (data parallel over RCCL, weak scaling, one process per GPU).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|infer|gta] [--attention sma|lsa]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
+
+--workload infer = configs[3] (autoregressive inference(), B=32, 1000 decoder steps, stop disabled; metric
+decode_steps_per_sec), --workload gta = configs[4] (teacher-forced forward under no_grad, eval, B=128/GPU; replicas
+only, no collective).  The default train line also carries a short "decode" measurement (N=1).
 
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline     dominant decoder kernel: algorithmic FLOPs per launch / its average duration,
@@ -84,15 +88,111 @@ def cpu_baseline(B=64, Tin=100, Tsub=60, T=16, reps=1):
                        f"best of {reps + 1} ({best:.2f} s)")
 
 
+def decode_bench(model, hp, B, Tin, Tsub, steps, reps, seed=77):
+    """Autoregressive inference() (BASELINE configs[3]): stop rule disabled, `steps` decoder steps per call."""
+    from tacotron2_subword_amd import train as T
+    b = T.synthetic_batch(hp, B, Tin, Tsub, 8, seed=seed)
+    ids, sub, pcls, bcls = b[0].cuda(), b[6].cuda(), b[7].cuda(), b[8].cuda()
+    was_training = model.training
+    model.eval()
+    old = model.decoder.gate_threshold, model.decoder.max_decoder_steps
+    model.decoder.gate_threshold, model.decoder.max_decoder_steps = 2.0, steps
+    try:
+        with torch.no_grad():
+            model.inference(ids, sub, pcls, bcls)            # warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                out = model.inference(ids, sub, pcls, bcls)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+    finally:
+        model.decoder.gate_threshold, model.decoder.max_decoder_steps = old
+        model.train(was_training)
+    assert out[0].shape[2] == steps
+    return dict(batch=B, steps_per_call=steps, ms_per_call=round(1e3 * dt, 2), steps_per_sec=round(steps / dt, 1),
+                frames_per_sec=round(B * steps / dt, 1), us_per_step=round(1e6 * dt / steps, 2))
+
+
+def side_workload(a, rank, world, local):
+    """--workload infer / gta: replicas only (no collective on the data path), one JSON line from rank 0."""
+    from tacotron2_subword_amd import _lib as L
+    from tacotron2_subword_amd.hparams import create_hparams
+    from tacotron2_subword_amd import train as T
+    L.set_precision(a.dtype)
+    hp = create_hparams()
+    if a.attention == "lsa":
+        hp.attention = "LSA"
+    hp.distributed_run = False
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+    model = T.load_model(hp)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    if a.workload == "infer":
+        B = a.batch or 32
+        steps_per_call = a.frames or 1000
+        model.eval()
+        b = T.synthetic_batch(hp, B, a.tin, a.tsub, 8, seed=1234 + rank)
+        ids, sub, pcls, bcls = b[0].cuda(), b[6].cuda(), b[7].cuda(), b[8].cuda()
+        model.decoder.gate_threshold, model.decoder.max_decoder_steps = 2.0, steps_per_call
+        run = lambda: model.inference(ids, sub, pcls, bcls)
+        units, metric, unit = steps_per_call, "decode_steps_per_sec", "decoder-steps/s"
+        desc = (f"BERT_Tacotron2.inference() B={B}/GPU, stop rule disabled, {steps_per_call} decoder steps per call "
+                f"({a.tin} phones, {a.tsub} sub-word tokens); one bench step = one call")
+    else:
+        B = a.batch or 128
+        Tn = a.frames or 400
+        model.eval()
+        batch = T.synthetic_batch(hp, B, a.tin, a.tsub, Tn, seed=1234 + rank)
+        x, y = model.parse_batch(batch)
+        run = lambda: model(x)
+        units, metric, unit = B * Tn, "mel_frames_per_sec_gta", "mel-frames/s"
+        desc = (f"GTA teacher-forced forward (no_grad, eval), B={B}/GPU, {a.tin} phones, {a.tsub} sub-word tokens, "
+                f"{Tn} frames; one bench step = one forward")
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            run()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            run()
+        sync()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+        torch.distributed.barrier()
+    if rank != 0:
+        return
+    out = {"metric": metric, "value": round(world * units * a.steps / dt, 1), "unit": unit, "n_gpus": world, "steps": a.steps,
+           "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 2), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+           "config": {"workload": desc, "attention": hp.attention, "global_batch": world * B, "parallelism": f"replicas x{world}"}}
+    if a.workload == "infer":
+        out["frames_per_sec"] = round(world * B * units * a.steps / dt, 1)
+        out["us_per_decoder_step"] = round(1e6 * dt / (a.steps * units), 2)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 64 train, 32 infer, 128 gta)")
     ap.add_argument("--tin", type=int, default=100)
     ap.add_argument("--tsub", type=int, default=60)
-    ap.add_argument("--frames", type=int, default=400)
+    ap.add_argument("--frames", type=int, default=0, help="frames per item (default 400; infer: decoder steps per call, default 1000)")
+    ap.add_argument("--workload", choices=["train", "infer", "gta"], default="train")
+    ap.add_argument("--attention", choices=["sma", "lsa"], default="sma",
+                    help="sma = the reference's default hparams (StepwiseMonotonicAttention); lsa = LocationSensitiveAttention")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16",
                     help="GEMM operand type: f32 = exact fp32 (parity path); bf16 = bf16 operands, fp32 accumulate/state")
@@ -106,6 +206,9 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+    if a.workload != "train":
+        return side_workload(a, rank, world, local)
+    a.batch, a.frames = a.batch or 64, a.frames or 400
 
     from tacotron2_subword_amd import _lib as L
     from tacotron2_subword_amd.hparams import create_hparams
@@ -113,6 +216,8 @@ def main():
 
     L.set_precision(a.dtype)
     hp = create_hparams()
+    if a.attention == "lsa":
+        hp.attention = "LSA"
     hp.distributed_run = world > 1
     if world > 1:
         import torch.distributed as dist
@@ -193,18 +298,22 @@ def main():
         "metric": "mel_frames_per_sec_train", "value": round(frames / dt, 1), "unit": "mel-frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": f"BERT_Tacotron2 default hparams (SMA), full training iteration fwd+loss+bwd+clip+Adam, "
+        "config": {"workload": f"BERT_Tacotron2 default hparams ({'SMA' if a.attention == 'sma' else 'LSA'}), full training iteration fwd+loss+bwd+clip+Adam, "
                                f"B={B}/GPU, {Tin} phones, {Tsub} sub-word tokens, {Tn} frames, 80-mel",
                    "global_batch": world * B, "frames_per_item": Tn, "parallelism": f"dp{world}",
                    "hip_kernels": "embeddings, encoder conv/BN + BiLSTM, converters, decoder (prenets, attention LSTMs, SMA, "
                                   "decoder LSTM, projections), postnet conv/BN: forward and backward",
                    "torch_ops": "loss reductions, clip_grad_norm_, Adam, cat/transpose copies",
-                   "precision": ("bf16 operands / fp32 accumulate for the large GEMMs (hoisted LSTM input halves, convolutions, "
-                                 "projections, weight gradients); per-step recurrent GEMMs, LSTM state, BatchNorm statistics and "
-                                 "attention recurrences fp32") if a.dtype == "bf16" else "fp32 everywhere (the parity path)"},
+                   "precision": ("bf16 operands / fp32 accumulate for every GEMM (hoisted LSTM input halves, per-step recurrent "
+                                 "LSTM GEMMs via bf16 weight/activation shadows, convolutions, projections, weight gradients); "
+                                 "LSTM gates/state, BatchNorm statistics, attention energies/recurrences, master weights, "
+                                 "gradients and Adam fp32") if a.dtype == "bf16" else "fp32 everywhere (the parity path)"},
         "loss": round(loss_val, 5),
         "roofline": roof, "kernels": kernels,
     }
+    if world == 1:
+        # "decode steps/sec" half of BASELINE.json's metric: a bounded run of configs[3] (B=32, stop disabled)
+        out["decode"] = decode_bench(model, hp, 32, Tin, Tsub, steps=250, reps=2)
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)

@@ -303,13 +303,6 @@ int processed_memory(const Dec& c) {
     return gemm(h, c.s);
 }
 
-__global__ void stop_check_kernel(const float* gate, long ldgate, int t, int B, float thr, int32_t* stop_index, int32_t* done) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B && stop_index[b] < 0) {
-        const float g = gate[(long)b * ldgate + t];
-        if (1.0f / (1.0f + expf(-g)) > thr) { stop_index[b] = t; atomicAdd(done, 1); }
-    }
-}
 __global__ void init_stop_kernel(int32_t* stop_index, int32_t* done, int B) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) stop_index[b] = -1;
@@ -675,24 +668,37 @@ int t2_decoder_infer(const t2_dims* dims, const t2_decoder_weights* w, const t2_
 
     hipLaunchKernelGGL(init_stop_kernel, dim3((z.B + 63) / 64), dim3(64), 0, c.s, a->stop_index, a->done_count, z.B);
     T2_LAUNCH_CHECK();
-    T2_TRY(fill_f32(c.P(L.x), 0.f, (size_t)z.B * z.M, c.s));      // go frame (model.py:444-445), rows [B][M] contiguous
     T2_TRY(processed_memory(c));
+    // one launch per step for projection + stop rule + the next step's prenets (infer.hip)
+    auto tail = [&](int t, bool proj) -> int {
+        StepTailDesc d{};
+        d.B = z.B; d.M = z.M; d.P = z.P; d.WO = z.WO; d.NS = z.NS; d.t = t;
+        d.do_proj = proj; d.do_prenet = proj ? (t + 1 < T) : 1;
+        const int tn = proj ? t + 1 : 0;                             // the step whose prenet outputs are produced
+        if (proj) {
+            d.dout = c.P(L.dout) + c.R(t) * z.WO; d.lddout = z.WO;
+            d.proj_w = w->proj_w; d.proj_b = w->proj_b; d.gate_w = w->gate_w; d.gate_b = w->gate_b;
+            d.mel_out = a->mel_out + (long)t * z.M; d.ldmel = (long)T * z.M;
+            d.gate_out = a->gate_out + t; d.ldgate = T;
+            d.thr = a->gate_threshold; d.stop_index = a->stop_index; d.done = a->done_count;
+        }
+        for (int s = 0; s < z.NS; ++s) {
+            d.w1[s] = s ? w->prenet_sub_w1 : w->prenet_w1; d.w2[s] = s ? w->prenet_sub_w2 : w->prenet_w2;
+            d.p1[s] = c.P(s ? L.p1s : L.p1) + c.R(tn) * z.P; d.p2[s] = c.P(s ? L.p2s : L.p2) + c.R(tn) * z.P;
+            d.site1[s] = s ? T2_SITE_PRENET1_SUB : T2_SITE_PRENET1; d.site2[s] = s ? T2_SITE_PRENET2_SUB : T2_SITE_PRENET2;
+        }
+        d.ldp = z.P;
+        d.drop_p = c.prenet_dropout ? dims->p_prenet_dropout : 0.f; d.seed = c.seed;
+        d.drop_base = (uint32_t)(c.R(tn) * z.P); d.drop_mstride = (uint32_t)z.P;      // logical [T,B,P]
+        return step_tail(d, c.s);
+    };
     int steps = 0;
+    T2_TRY(tail(0, false));                                          // prenet of the go frame (model.py:444-450)
     for (int t = 0; t < T; ++t) {
-        // prenet of the previous output frame (model.py:449-450,470-471)
-        const float* X = t == 0 ? c.P(L.x) : a->mel_out + (long)(t - 1) * z.M;
-        const long ldx = t == 0 ? z.M : (long)T * z.M;
-        const uint32_t base = (uint32_t)(c.R(t) * z.P), mstride = (uint32_t)z.P;
-        T2_TRY(prenet(c, false, X, ldx, z.B, c.P(L.p1) + c.R(t) * z.P, c.P(L.p2) + c.R(t) * z.P, z.P, base, mstride));
-        if (z.NS == 2) T2_TRY(prenet(c, true, X, ldx, z.B, c.P(L.p1s) + c.R(t) * z.P, c.P(L.p2s) + c.R(t) * z.P, z.P, base, mstride));
         T2_TRY(att_lstm_step(c, t));
         T2_TRY(attention_step(c, t));
         T2_TRY(dec_lstm_step(c, t));
-        T2_TRY(projection(c, c.P(L.dout) + c.R(t) * z.WO, z.WO, z.B, a->mel_out + (long)t * z.M, (long)T * z.M,
-                          a->gate_out + t, T, false));
-        hipLaunchKernelGGL(stop_check_kernel, dim3((z.B + 63) / 64), dim3(64), 0, c.s, a->gate_out, (long)T, t, z.B,
-                           a->gate_threshold, a->stop_index, a->done_count);
-        T2_LAUNCH_CHECK();
+        T2_TRY(tail(t, true));                                       // mel_t, gate_t, stop rule, prenets of step t+1 (:470-471)
         steps = t + 1;
         if (steps % poll == 0 || steps == T) {
             int32_t done = 0;

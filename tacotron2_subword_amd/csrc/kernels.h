@@ -146,6 +146,23 @@ struct AttnBwdStream {
 struct AttnBwdDesc { AttnBwdStream st[2]; int nstreams; int B, A, E; int first; int kind, F, Kc; };
 int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s);
 
+// ------------------------------------------------------------------ decode-step tail (infer.hip)
+// projection + stop rule of step t and both prenets of step t+1, one workgroup per batch item
+struct StepTailDesc {
+    int B, M, P, WO, NS, t;
+    int do_proj, do_prenet;
+    const float* dout; long lddout;                 // [B,WO] rows [dec_h | ctx | ctx_sub]
+    const float* proj_w; const float* proj_b; const float* gate_w; const float* gate_b;
+    float* mel_out; long ldmel; float* gate_out; long ldgate;
+    float thr; int32_t* stop_index; int32_t* done;  // stop_index nullable = no stop rule
+    const float* x_in; long ldx_in;                 // do_proj == 0: prenet input rows [B,M] (null = zeros, the go frame)
+    const float* w1[2]; const float* w2[2];         // prenet weights [P,M], [P,P] per stream
+    float* p1[2]; float* p2[2]; long ldp;           // [B,P] outputs (p1 nullable)
+    __bf16* p2_16[2]; long ldp16;                   // optional bf16 copy of p2
+    float drop_p; uint64_t seed; uint32_t site1[2], site2[2]; uint32_t drop_base, drop_mstride;   // keep index = base + b*mstride + n
+};
+int step_tail(const StepTailDesc& d, hipStream_t s);
+
 // ------------------------------------------------------------------ conv + BN stacks, embedding (conv.hip)
 struct ConvBnFwd {
     const float* x; int B, T, Cin, Cout, K;      // x: [B*T, Cin] channels-last frames
