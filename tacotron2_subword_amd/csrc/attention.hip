@@ -204,6 +204,7 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
             st.ctx1[(long)b * st.ldctx1 + c] = sum;
             if (st.ctx2) st.ctx2[(long)b * st.ldctx2 + c] = sum;
             if (st.ctx16) st.ctx16[(long)b * st.ldctx16 + c] = (__bf16)sum;
+            if (st.ctx16b) st.ctx16b[(long)b * st.ldctx16b + c] = (__bf16)sum;
         }
     }
 }

@@ -77,6 +77,25 @@ int check_dims(const t2_dims& d) {
 
 size_t align4(size_t n) { return (n + 3) & ~(size_t)3; }
 
+// Decode loop, bf16-operand mode: whole-cell weight shadows [W_hh | W_ih[:,P:] | W_ih[:,:P]] (attention LSTMs) and
+// [W_ih | W_hh] (decoder LSTM) so that each cell is ONE K-contiguous product, plus the bf16 input rows the producing
+// kernels write: att rows [2][NS][B][Ha+E+P] = [h | ctx | prenet], dec rows [2][B][WD+Hd] = [att_h | ctx | ... | dec_h],
+// ping-pong on step parity (step t reads buffer t&1 and writes the recurrent parts into (t+1)&1).
+struct InferShadows {
+    int Ka, Kd; size_t wa[2], wd, rows_a, rows_d, total_floats;
+};
+InferShadows infer_shadows(const Sizes& z, size_t base) {
+    InferShadows m{};
+    m.Ka = z.Ha + z.E + z.P; m.Kd = z.WD + z.Hd;
+    size_t off = base;
+    auto take = [&](size_t elems) { size_t o = off; off += align4((elems + 1) / 2); return o; };
+    m.wa[0] = take((size_t)4 * z.Ha * m.Ka); m.wa[1] = take((size_t)4 * z.Ha * m.Ka);
+    m.wd = take((size_t)4 * z.Hd * m.Kd);
+    m.rows_a = take((size_t)2 * 2 * z.B * m.Ka); m.rows_d = take((size_t)2 * z.B * m.Kd);
+    m.total_floats = off - base;
+    return m;
+}
+
 void layout_of(const t2_dims& d, const Sizes& z, t2_decoder_layout* L) {
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += align4(n); return o; };
@@ -95,9 +114,13 @@ void layout_of(const t2_dims& d, const Sizes& z, t2_decoder_layout* L) {
     L->dout = take(BT * z.WO);
     L->qs = take(BT * z.A); L->qss = take(BT * z.A);
     L->qpart = take((size_t)2 * (z.Ha / 8) * z.B * z.A);
+    // bf16 shadow arena: teacher-forced passes keep [W_hh | W_ih[:,P:]] (+ transposes) per attention stream and W_hh of
+    // the decoder LSTM; the decode loop keeps whole-cell shadows and ping-pong input rows (InferShadows) in the same space
     const size_t na = (size_t)4 * z.Ha * (z.Ha + z.E) / 2, nd = (size_t)4 * z.Hd * z.Hd / 2;      // bf16 pairs per float
-    L->w16a = take(na); L->w16as = take(na); L->w16d = take(nd);
-    L->wt16a = take(na); L->wt16as = take(na); L->wt16d = take(nd);
+    const size_t train16 = 4 * na + 2 * nd, infer16 = infer_shadows(z, 0).total_floats;
+    const size_t arena = take(train16 > infer16 ? train16 : infer16);
+    L->w16a = arena; L->w16as = arena + na; L->w16d = arena + 2 * na;
+    L->wt16a = L->w16d + nd; L->wt16as = L->wt16a + na; L->wt16d = L->wt16as + na;
     L->din16 = take(BT * z.WD / 2 + 4); L->dh16 = take(BT * z.Hd / 2 + 4);
     L->gemm_ws_floats = (size_t)16 << 20;                     // 64 MiB of split-K scratch
     L->gemm_ws = take(L->gemm_ws_floats);
@@ -109,7 +132,10 @@ struct Dec {
     const float* memory; const float* memory_sub; const int32_t* len; const int32_t* len_sub;
     float* mel_out; float* gate_out; float* align; float* align_sub;
     bool training; bool prenet_dropout; bool teacher; uint64_t seed; hipStream_t s;
-    bool use16 = false;                              // bf16-operand recurrent steps (t2_set_precision(1), teacher-forced)
+    bool use16 = false;                              // bf16-operand recurrent steps (t2_set_precision(1))
+    InferShadows I{};                                // decode loop only (teacher == false && use16)
+    __bf16* RowA(int parity, int s) const { return reinterpret_cast<__bf16*>(ws + I.rows_a) + (size_t)(parity * 2 + s) * z.B * I.Ka; }
+    __bf16* RowD(int parity) const { return reinterpret_cast<__bf16*>(ws + I.rows_d) + (size_t)parity * z.B * I.Kd; }
     float* P(size_t off) const { return ws + off; }
     __bf16* P16(size_t off) const { return reinterpret_cast<__bf16*>(ws + off); }
     long R(int t) const { return (long)t * z.B; }      // first row of step t in a time-major [T,B,*] buffer
@@ -196,7 +222,12 @@ int att_lstm_step(const Dec& c, int t) {
         st.idx_base = (uint32_t)(c.R(t) * z.Ha); st.idx_bstride = (uint32_t)z.Ha;       // logical [T,B,Ha]
         st.wq = s ? c.w.attn_sub.wq : c.w.attn.wq; st.A = z.A;
         st.qpart = c.P(L.qpart) + (size_t)s * (z.Ha / 8) * z.B * z.A;
-        if (c.use16) {                               // one K-contiguous bf16 segment [h | ctx] x [W_hh | W_ih[:,P:]]
+        if (c.use16 && !c.teacher) {                 // decode loop: [h | ctx | prenet] x [W_hh | W_ih[:,P:] | W_ih[:,:P]]
+            st.nseg = 0;
+            st.x16 = c.RowA(t & 1, s); st.ldx16 = c.I.Ka; st.w16 = c.P16(c.I.wa[s]); st.ldw16 = c.I.Ka; st.k16 = c.I.Ka;
+            st.h16_out = c.RowA((t + 1) & 1, s); st.ldh16 = c.I.Ka;
+            st.h16_out2 = c.RowD(t & 1) + hoff; st.ldh16_2 = c.I.Kd;
+        } else if (c.use16) {                        // one K-contiguous bf16 segment [h | ctx] x [W_hh | W_ih[:,P:]]
             __bf16* D16 = c.P16(L.din16);
             st.nseg = 0;
             st.x16 = D16 + (t > 0 ? c.R(t - 1) * z.WD + hoff : 0); st.ldx16 = z.WD;
@@ -237,7 +268,10 @@ int attention_step(const Dec& c, int t) {
         }
         st.ctx1 = c.P(L.din) + c.R(t) * z.WD + ((s ? z.Ha + z.E : 0) + z.Ha); st.ldctx1 = z.WD;
         st.ctx2 = c.P(L.dout) + c.R(t) * z.WO + z.Hd + (s ? z.E : 0); st.ldctx2 = z.WO;
-        if (c.use16) { st.ctx16 = c.P16(L.din16) + c.R(t) * z.WD + ((s ? z.Ha + z.E : 0) + z.Ha); st.ldctx16 = z.WD; }
+        if (c.use16 && !c.teacher) {
+            st.ctx16 = c.RowA((t + 1) & 1, s) + z.Ha; st.ldctx16 = c.I.Ka;
+            st.ctx16b = c.RowD(t & 1) + (s ? z.Ha + z.E : 0) + z.Ha; st.ldctx16b = c.I.Kd;
+        } else if (c.use16) { st.ctx16 = c.P16(L.din16) + c.R(t) * z.WD + ((s ? z.Ha + z.E : 0) + z.Ha); st.ldctx16 = z.WD; }
         st.v = aw.v; st.loc_conv = aw.loc_conv; st.loc_dense = aw.loc_dense;
         st.site_noise = s ? T2_SITE_NOISE_SUB : T2_SITE_NOISE;
         st.idx_base = (uint32_t)(c.R(t) * Tin); st.idx_bstride = (uint32_t)Tin;          // logical [T,B,Tin]
@@ -270,7 +304,11 @@ int dec_lstm_step(const Dec& c, int t) {
     st.h_out = c.P(L.dout) + c.R(t) * z.WO; st.ldh_out = z.WO;
     st.site_h = T2_SITE_DEC_H; st.site_c = T2_SITE_DEC_C;
     st.idx_base = (uint32_t)(c.R(t) * z.Hd); st.idx_bstride = (uint32_t)z.Hd;             // logical [T,B,Hd]
-    if (c.use16) {
+    if (c.use16 && !c.teacher) {                     // decode loop: [att_h | ctx | att_h_sub | ctx_sub | dec_h] x [W_ih | W_hh]
+        st.nseg = 0;
+        st.x16 = c.RowD(t & 1); st.ldx16 = c.I.Kd; st.w16 = c.P16(c.I.wd); st.ldw16 = c.I.Kd; st.k16 = c.I.Kd;
+        st.h16_out = c.RowD((t + 1) & 1) + z.WD; st.ldh16 = c.I.Kd;
+    } else if (c.use16) {
         __bf16* H16 = c.P16(L.dh16);
         st.nseg = 0;
         st.x16 = H16 + (t > 0 ? c.R(t - 1) * z.Hd : 0); st.ldx16 = z.Hd;
@@ -669,6 +707,23 @@ int t2_decoder_infer(const t2_dims* dims, const t2_decoder_weights* w, const t2_
     hipLaunchKernelGGL(init_stop_kernel, dim3((z.B + 63) / 64), dim3(64), 0, c.s, a->stop_index, a->done_count, z.B);
     T2_LAUNCH_CHECK();
     T2_TRY(processed_memory(c));
+    c.I = infer_shadows(z, L.w16a);
+    c.use16 = get_precision() == 1 && z.B <= 64 && c.I.Ka % 256 == 0 && c.I.Kd % 256 == 0;
+    if (c.use16) {
+        const long ldi = z.P + z.E;
+        for (int s = 0; s < z.NS; ++s) {
+            const t2_lstm_weights& lw = s ? w->att_sub : w->att;
+            __bf16* f = c.P16(c.I.wa[s]);
+            T2_TRY(cast_rows_bf16(lw.w_hh, z.Ha, f, c.I.Ka, 4 * z.Ha, z.Ha, c.s));
+            T2_TRY(cast_rows_bf16(lw.w_ih + z.P, ldi, f + z.Ha, c.I.Ka, 4 * z.Ha, z.E, c.s));
+            T2_TRY(cast_rows_bf16(lw.w_ih, ldi, f + z.Ha + z.E, c.I.Ka, 4 * z.Ha, z.P, c.s));
+        }
+        T2_TRY(cast_rows_bf16(w->dec.w_ih, z.WD, c.P16(c.I.wd), c.I.Kd, 4 * z.Hd, z.WD, c.s));
+        T2_TRY(cast_rows_bf16(w->dec.w_hh, z.Hd, c.P16(c.I.wd) + z.WD, c.I.Kd, 4 * z.Hd, z.Hd, c.s));
+        // zero recurrent state of step 0: h, ctx (attention rows) and dec_h (decoder rows)
+        T2_CHECK_HIP(hipMemsetAsync(c.RowA(0, 0), 0, (size_t)2 * 2 * z.B * c.I.Ka * sizeof(__bf16), c.s));
+        T2_CHECK_HIP(hipMemsetAsync(c.RowD(0), 0, (size_t)2 * z.B * c.I.Kd * sizeof(__bf16), c.s));
+    }
     // one launch per step for projection + stop rule + the next step's prenets (infer.hip)
     auto tail = [&](int t, bool proj) -> int {
         StepTailDesc d{};
@@ -688,6 +743,7 @@ int t2_decoder_infer(const t2_dims* dims, const t2_decoder_weights* w, const t2_
             d.site1[s] = s ? T2_SITE_PRENET1_SUB : T2_SITE_PRENET1; d.site2[s] = s ? T2_SITE_PRENET2_SUB : T2_SITE_PRENET2;
         }
         d.ldp = z.P;
+        if (c.use16) { for (int s = 0; s < z.NS; ++s) d.p2_16[s] = c.RowA(tn & 1, s) + z.Ha + z.E; d.ldp16 = c.I.Ka; }
         d.drop_p = c.prenet_dropout ? dims->p_prenet_dropout : 0.f; d.seed = c.seed;
         d.drop_base = (uint32_t)(c.R(tn) * z.P); d.drop_mstride = (uint32_t)z.P;      // logical [T,B,P]
         return step_tail(d, c.s);

@@ -56,6 +56,7 @@ struct LstmStream {
     // bf16-operand mode (one K-contiguous segment): x16 [B,k16] and w16 [4H,k16] shadows; h16_out = bf16 copy of h
     const __bf16* x16; long ldx16; const __bf16* w16; long ldw16; int k16;
     __bf16* h16_out; long ldh16;
+    __bf16* h16_out2; long ldh16_2;       // second bf16 destination (decode loop: the decoder LSTM's input row)
 };
 constexpr int kMaxLstmStreams = 4;
 struct LstmStepDesc { LstmStream st[kMaxLstmStreams]; int nstreams; int B, H; float drop_p; uint64_t seed; };
@@ -109,6 +110,7 @@ struct AttnStream {
     float* ctx1; long ldctx1;             // [B,E]
     float* ctx2; long ldctx2;             // second destination (nullable)
     __bf16* ctx16; long ldctx16;          // bf16 copy for the bf16-operand LSTM step (nullable)
+    __bf16* ctx16b; long ldctx16b;        // second bf16 destination (decode loop)
     const float* v;                       // [A]
     const float* loc_conv; const float* loc_dense;   // LSA: [F,2,Kc], [A,F]
     uint32_t site_noise; uint32_t idx_base, idx_bstride;   // SMA noise index = idx_base + b*idx_bstride + j

@@ -184,6 +184,7 @@ __device__ __forceinline__ void lstm_tail(const LstmStepDesc& d, const LstmStrea
                 if (st.h_out2) st.h_out2[(long)b * st.ldh_out2 + u] = ho;
                 st.c_out[(long)b * st.ldc_out + u] = co;
                 if (st.h16_out) st.h16_out[(long)b * st.ldh16 + u] = (__bf16)ho;
+                if (st.h16_out2) st.h16_out2[(long)b * st.ldh16_2 + u] = (__bf16)ho;
                 hs[b * HU + uu] = ho;
             }
         }

@@ -194,6 +194,27 @@ def test_bf16_operand_mode_stays_close_to_fp32_golden():
     assert errs["mel"] < 0.1 and errs["mel_postnet"] < 0.15 and errs["align"] < 0.1
 
 
+@pytest.mark.parametrize("att,name", [(SMA, "sma_infer"), (LSA, "lsa_infer")])
+def test_bf16_decode_loop_stays_close_to_fp32_golden(att, name):
+    """bf16-operand decode loop (whole-cell weight shadows, bf16 input rows): outputs stay near the fp32 golden frames."""
+    from tacotron2_subword_amd import _lib as L
+    g = load_golden(name)
+    _, Tin, Tsub, steps = (int(v) for v in g["meta"])
+    m, hps = build_model(att)
+    b = recipe.make_batch(hp_for(att), 1, Tin, Tsub, 8, seed=4321, ragged=False)
+    ids, sub, pcls, bcls = b[0].cuda(), b[6].cuda(), b[7].cuda(), b[8].cuda()
+    m.decoder.gate_threshold, m.decoder.max_decoder_steps = 2.0, steps
+    L.set_precision("bf16")
+    try:
+        r = m.inference(ids, sub, pcls, bcls)
+        torch.cuda.synchronize()
+    finally:
+        L.set_precision("f32")
+    assert tuple(r[0].shape) == g["fixed_mel"].shape
+    assert maxabs(r[0], g["fixed_mel"]) < 0.05 and maxabs(r[1], g["fixed_mel_postnet"]) < 0.1
+    assert maxabs(r[3], g["fixed_align"]) < 0.02
+
+
 def test_bf16_mode_gradients_track_fp32():
     """Same batch, same RNG seeds: the bf16-operand mode (large GEMMs and the recurrent step GEMMs in bf16,
     fp32 accumulate/state) must give gradients close to the fp32 parity path in norm."""
