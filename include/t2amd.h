@@ -98,6 +98,7 @@ typedef struct t2_decoder_layout {
     size_t dout;                      /* [T,B, Hd+2*E] = dec_h | ctx | ctx_sub */
     size_t qs, qss;                   /* processed query per step [T,B,A] */
     size_t qpart;                     /* per-step scratch [2][Ha/8][B][A] */
+    size_t w1t;                       /* decode loop: transposed first prenet layers [2][n_mel][P] */
     /* bf16-operand mode (sizes in floats = bf16 elements / 2): weight shadows [W_hh | W_ih[:,P:]] per stream,
      * decoder W_hh, their transposes for the backward pass, and bf16 copies of DIN / dec_h */
     size_t w16a, w16as, w16d, wt16a, wt16as, wt16d, din16, dh16;

@@ -8,6 +8,7 @@ from tacotron2_subword_amd import _lib as L, ops
 hp = hp_for(SMA); P = to_dev(recipe.make_weights(hp)); dims = L.dims_from_hparams(hp)
 W = L.decoder_weights(P, dims.attention_kind)
 B, T = 64, 24
+L.set_precision(os.environ.get("T2_PREC", "bf16"))
 mem = torch.randn(B, 100, 512, device="cuda") * .5; mems = torch.randn(B, 60, 512, device="cuda") * .5
 mels = torch.randn(B, 80, T, device="cuda"); tl = torch.full((B,), 100, device="cuda"); bl = torch.full((B,), 60, device="cuda")
 for _ in range(3):
@@ -20,3 +21,5 @@ for name, o in (("att (2 streams)", 0), ("dec", 8)):
     v = [buf[o + i] for i in range(5)]
     print(name, "entry->staged %.2f us | K loop %.2f us | epilogue %.2f us | query partials %.2f us | total %.2f us" % tuple(
         [(v[i + 1] - v[i]) / 100.0 for i in range(4)] + [(v[4] - v[0]) / 100.0]))
+    print("   probes: first weight elem %.2f us | first activation elem %.2f us | second of each %.2f us | rest of fill %.2f us" % (
+        (buf[o + 5] - v[0]) / 100.0, (buf[o + 6] - buf[o + 5]) / 100.0, (buf[o + 7] - buf[o + 6]) / 100.0, (v[1] - buf[o + 7]) / 100.0))

@@ -46,7 +46,7 @@ class DecoderWeights(C.Structure):
 
 _LAYOUT_FIELDS = ["total_floats", "x", "p1", "p2", "p1s", "p2s", "pm", "pms", "prea", "preas", "ga", "gas",
                   "cna", "cnas", "ca", "cas", "din", "psel", "psels", "wcum", "wcums", "pred", "gd", "cnd", "cd",
-                  "dout", "qs", "qss", "qpart", "w16a", "w16as", "w16d", "wt16a", "wt16as", "wt16d", "din16", "dh16",
+                  "dout", "qs", "qss", "qpart", "w1t", "w16a", "w16as", "w16d", "wt16a", "wt16as", "wt16d", "din16", "dh16",
                   "gemm_ws", "gemm_ws_floats"]
 
 

@@ -114,6 +114,7 @@ void layout_of(const t2_dims& d, const Sizes& z, t2_decoder_layout* L) {
     L->dout = take(BT * z.WO);
     L->qs = take(BT * z.A); L->qss = take(BT * z.A);
     L->qpart = take((size_t)2 * (z.Ha / 8) * z.B * z.A);
+    L->w1t = take((size_t)2 * z.M * z.P);
     // bf16 shadow arena: teacher-forced passes keep [W_hh | W_ih[:,P:]] (+ transposes) per attention stream and W_hh of
     // the decoder LSTM; the decode loop keeps whole-cell shadows and ping-pong input rows (InferShadows) in the same space
     const size_t na = (size_t)4 * z.Ha * (z.Ha + z.E) / 2, nd = (size_t)4 * z.Hd * z.Hd / 2;      // bf16 pairs per float
@@ -707,6 +708,8 @@ int t2_decoder_infer(const t2_dims* dims, const t2_decoder_weights* w, const t2_
     hipLaunchKernelGGL(init_stop_kernel, dim3((z.B + 63) / 64), dim3(64), 0, c.s, a->stop_index, a->done_count, z.B);
     T2_LAUNCH_CHECK();
     T2_TRY(processed_memory(c));
+    for (int s = 0; s < z.NS; ++s)                                   // W1 [P,M] -> [M,P]: coalesced thread-per-output reads
+        T2_TRY(permute_rows(s ? w->prenet_sub_w1 : w->prenet_w1, c.P(L.w1t) + (size_t)s * z.M * z.P, z.P, z.M, 1, c.s));
     c.I = infer_shadows(z, L.w16a);
     c.use16 = get_precision() == 1 && z.B <= 64 && c.I.Ka % 256 == 0 && c.I.Kd % 256 == 0;
     if (c.use16) {
@@ -738,7 +741,7 @@ int t2_decoder_infer(const t2_dims* dims, const t2_decoder_weights* w, const t2_
             d.thr = a->gate_threshold; d.stop_index = a->stop_index; d.done = a->done_count;
         }
         for (int s = 0; s < z.NS; ++s) {
-            d.w1[s] = s ? w->prenet_sub_w1 : w->prenet_w1; d.w2[s] = s ? w->prenet_sub_w2 : w->prenet_w2;
+            d.w1t[s] = c.P(L.w1t) + (size_t)s * z.M * z.P; d.w2[s] = s ? w->prenet_sub_w2 : w->prenet_w2;
             d.p1[s] = c.P(s ? L.p1s : L.p1) + c.R(tn) * z.P; d.p2[s] = c.P(s ? L.p2s : L.p2) + c.R(tn) * z.P;
             d.site1[s] = s ? T2_SITE_PRENET1_SUB : T2_SITE_PRENET1; d.site2[s] = s ? T2_SITE_PRENET2_SUB : T2_SITE_PRENET2;
         }

@@ -158,7 +158,7 @@ struct StepTailDesc {
     float* mel_out; long ldmel; float* gate_out; long ldgate;
     float thr; int32_t* stop_index; int32_t* done;  // stop_index nullable = no stop rule
     const float* x_in; long ldx_in;                 // do_proj == 0: prenet input rows [B,M] (null = zeros, the go frame)
-    const float* w1[2]; const float* w2[2];         // prenet weights [P,M], [P,P] per stream
+    const float* w1t[2]; const float* w2[2];        // prenet weights per stream: first layer TRANSPOSED [M,P], second [P,P]
     float* p1[2]; float* p2[2]; long ldp;           // [B,P] outputs (p1 nullable)
     __bf16* p2_16[2]; long ldp16;                   // optional bf16 copy of p2
     float drop_p; uint64_t seed; uint32_t site1[2], site2[2]; uint32_t drop_base, drop_mstride;   // keep index = base + b*mstride + n

@@ -25,7 +25,7 @@ __device__ unsigned long long t2_stamps[32];
 #define T2_STAMP(i)                                                                              \
     do {                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        if (blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x == 0 && d.st[0].t == 0 && d.st[0].nseg > 0) t2_stamps[(d.nstreams == 2 ? 0 : 8) + i] = __builtin_amdgcn_s_memrealtime(); \
+        if (blockIdx.x == 7 && blockIdx.y == 0 && threadIdx.x == 0) t2_stamps[(d.nstreams == 2 ? 0 : 8) + i] = __builtin_amdgcn_s_memrealtime(); \
         __builtin_amdgcn_sched_barrier(0);                                                       \
     } while (0)
 extern "C" int t2_debug_read_stamps(unsigned long long* out, int n) {
@@ -190,6 +190,7 @@ __device__ __forceinline__ void lstm_tail(const LstmStepDesc& d, const LstmStrea
         }
     }
 
+    T2_STAMP(3);
     if (st.wq) {
         // partial query projection of this unit group: qpart[group][b][a] = sum_uu h[b,u0+uu] * Wq[a,u0+uu]
         __syncthreads();
@@ -355,6 +356,7 @@ __global__ __launch_bounds__(NTH) void lstm_step_fwd_bf16_kernel(LstmStepDesc d)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hk = lane >> 5;
 
+    T2_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __bf16* As = reinterpret_cast<__bf16*>(smem);
     __bf16* Bs = As + TL::A_ELEMS;
@@ -367,13 +369,33 @@ __global__ __launch_bounds__(NTH) void lstm_step_fwd_bf16_kernel(LstmStepDesc d)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
 
+    // Two register stage buffers: stage c+2 is requested while stage c is computed and stage c+1 is still in
+    // flight, so a workgroup keeps two full stages (~2 x 64 KB) outstanding — the K loop is a chain of L2/MALL
+    // round trips and one stage of prefetch left the CU idle for most of each trip.
     const int nstages = st.k16 / BKT;
-    bf16x8 ra[TL::QA], rb[TL::QB];
-    auto load_stage = [&](int c) {
+#ifdef T2_STAMPS
+    {   // latency probes: one cold weight element, one cold activation element, one more of each (warm TLB?)
+        const volatile __bf16* wp = st.w16 + (long)u0 * st.ldw16;
+        float v0 = (float)wp[0];
+        __builtin_amdgcn_s_waitcnt(0);
+        T2_STAMP(5);
+        const volatile __bf16* xp = st.x16;
+        v0 += (float)xp[0];
+        __builtin_amdgcn_s_waitcnt(0);
+        T2_STAMP(6);
+        v0 += (float)wp[4096] + (float)xp[4096];
+        __builtin_amdgcn_s_waitcnt(0);
+        T2_STAMP(7);
+        if (v0 == 123.456f) hs[0] = v0;
+    }
+#endif
+    bf16x8 ra0[TL::QA], rb0[TL::QB], ra1[TL::QA], rb1[TL::QB];
+    auto load_stage = [&](int c, bf16x8 (&ra)[TL::QA], bf16x8 (&rb)[TL::QB]) {
         load_rows16<BKT, TL::QA>([&](int row, bool& ok) { ok = row < B; return st.x16 + (long)(ok ? row : 0) * st.ldx16; }, c * BKT, ra);
         load_rows16<BKT, TL::QB>([&](int n, bool& ok) { ok = true; return st.w16 + (long)((n >> 3) * H + u0 + (n & 7)) * st.ldw16; }, c * BKT, rb);
     };
-    if (nstages > 0) load_stage(0);
+    if (nstages > 0) load_stage(0, ra0, rb0);
+    if (nstages > 1) load_stage(1, ra1, rb1);
     constexpr bool kPrefetch = true;
     float pre_v[MT][4];
     float cp_v[MT];
@@ -393,16 +415,25 @@ __global__ __launch_bounds__(NTH) void lstm_step_fwd_bf16_kernel(LstmStepDesc d)
             cp_v[m] = st.c_prev ? st.c_prev[(long)b * st.ldc_prev + u] : 0.f;
         }
     }
-    if (nstages > 0) { store_rows16<BKT, TL::QA>(As, ra); store_rows16<BKT, TL::QB>(Bs, rb); }
+    if (nstages > 0) { store_rows16<BKT, TL::QA>(As, ra0); store_rows16<BKT, TL::QB>(Bs, rb0); }
     __syncthreads();
-    for (int c = 0; c < nstages; ++c) {
-        const bool more = c + 1 < nstages;
-        if (more) load_stage(c + 1);
+    T2_STAMP(1);
+    for (int c = 0; c < nstages; c += 2) {
+        if (c + 2 < nstages) load_stage(c + 2, ra0, rb0);
         compute_stage16<MT, BKT>(As, Bs, wave, r, hk, acc);
         __syncthreads();
-        if (more) { store_rows16<BKT, TL::QA>(As, ra); store_rows16<BKT, TL::QB>(Bs, rb); __syncthreads(); }
+        if (c + 1 < nstages) {
+            store_rows16<BKT, TL::QA>(As, ra1); store_rows16<BKT, TL::QB>(Bs, rb1);
+            __syncthreads();
+            if (c + 3 < nstages) load_stage(c + 3, ra1, rb1);
+            compute_stage16<MT, BKT>(As, Bs, wave, r, hk, acc);
+            __syncthreads();
+            if (c + 2 < nstages) { store_rows16<BKT, TL::QA>(As, ra0); store_rows16<BKT, TL::QB>(Bs, rb0); __syncthreads(); }
+        }
     }
+    T2_STAMP(2);
     lstm_tail<MT, kPrefetch>(d, st, u0, wave, r, hk, acc, part, hs, pre_v, cp_v);
+    T2_STAMP(4);
 }
 
 // ---------------------------------------------------------------------------------------------
