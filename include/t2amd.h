@@ -44,6 +44,9 @@ int t2_version(void);
  * staging); recurrent state, BatchNorm statistics and attention recurrences stay fp32. */
 int t2_set_precision(int mode);
 int t2_get_precision(void);
+/* 1 (default): teacher-forced passes run the decoder-LSTM chain on an internal side stream, one chunk of steps
+ * apart from the attention chain (fork/join inside the call; the caller's stream semantics are unchanged).  0: one stream. */
+int t2_set_overlap(int on);
 
 /* Model dimensions (hparams.py:55-95). */
 typedef struct t2_dims {

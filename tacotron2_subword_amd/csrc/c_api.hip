@@ -22,6 +22,7 @@ void t2_set_error(const char* fmt, ...) {
         if (rc_ != 0) return rc_;   \
     } while (0)
 
+#include <algorithm>
 #include <vector>
 
 using namespace t2;
@@ -49,6 +50,42 @@ struct ProfScope {
         if (on) { (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s); g_prof.used += 2; }
     }
 };
+
+// ---------------------------------------------------------------------------------------------
+// Side stream for the decoder-LSTM recurrence.  Teacher-forced passes have two serial chains that only meet through
+// hoisted GEMMs: (A) attention LSTMs + attention, (B) decoder LSTM.  Each per-step launch is bound by what ONE CU can
+// pull from L2/MALL and leaves much of the chip idle (the attention step uses B*2 workgroups, the decoder-LSTM step
+// H/8), so chain B runs on its own stream one chunk of steps behind (forward) / ahead of (backward) chain A.
+// The caller's stream forks at the first chunk and joins before the entry point returns.
+// ---------------------------------------------------------------------------------------------
+struct Side { hipStream_t s = nullptr; std::vector<hipEvent_t> ev; };
+static Side g_side[16];
+static int g_overlap = 1;
+static int side_get(Side** out) {
+    int dev = 0;
+    T2_CHECK_HIP(hipGetDevice(&dev));
+    Side& sd = g_side[dev & 15];
+    if (!sd.s) T2_CHECK_HIP(hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking));
+    *out = &sd;
+    return 0;
+}
+static int side_event(Side& sd, size_t i, hipEvent_t* out) {
+    while (sd.ev.size() <= i) {
+        hipEvent_t e;
+        T2_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        sd.ev.push_back(e);
+    }
+    *out = sd.ev[i];
+    return 0;
+}
+// record on `from`, make `to` wait
+static int stream_edge(Side& sd, size_t i, hipStream_t from, hipStream_t to) {
+    hipEvent_t e;
+    T2_TRY_RC(side_event(sd, i, &e));
+    T2_CHECK_HIP(hipEventRecord(e, from));
+    T2_CHECK_HIP(hipStreamWaitEvent(to, e, 0));
+    return 0;
+}
 
 namespace {
 
@@ -134,6 +171,7 @@ struct Dec {
     float* mel_out; float* gate_out; float* align; float* align_sub;
     bool training; bool prenet_dropout; bool teacher; uint64_t seed; hipStream_t s;
     bool use16 = false;                              // bf16-operand recurrent steps (t2_set_precision(1))
+    hipStream_t sd = nullptr;                        // stream of the decoder-LSTM chain (== s unless overlapped)
     InferShadows I{};                                // decode loop only (teacher == false && use16)
     __bf16* RowA(int parity, int s) const { return reinterpret_cast<__bf16*>(ws + I.rows_a) + (size_t)(parity * 2 + s) * z.B * I.Ka; }
     __bf16* RowD(int parity) const { return reinterpret_cast<__bf16*>(ws + I.rows_d) + (size_t)parity * z.B * I.Kd; }
@@ -316,8 +354,9 @@ int dec_lstm_step(const Dec& c, int t) {
         st.w16 = c.P16(L.w16d); st.ldw16 = z.Hd; st.k16 = t > 0 ? z.Hd : 0;
         st.h16_out = H16 + c.R(t) * z.Hd; st.ldh16 = z.Hd;
     }
-    ProfScope ps(PK_LSTM_DEC_FWD, c.s);
-    return lstm_step_fwd(d, c.s);
+    hipStream_t sd = c.sd ? c.sd : c.s;
+    ProfScope ps(PK_LSTM_DEC_FWD, sd);
+    return lstm_step_fwd(d, sd);
 }
 
 // mel / gate projection (model.py:382-388); permute_tb: rows come time-major, outputs are [B,T,*]
@@ -385,6 +424,7 @@ struct Bwd {
     float* S(size_t off) const { return a.bws + off; }
     long R(int t) const { return (long)t * z.B; }
     bool use16 = false;
+    hipStream_t sd = nullptr;                        // stream of the decoder-LSTM chain (== s unless overlapped)
     const __bf16* W16(size_t off) const { return reinterpret_cast<const __bf16*>(a.ws + off); }
     __bf16* S16(size_t off) const { return reinterpret_cast<__bf16*>(a.bws + off); }
     float* gemm_ws() const { return a.bws + BL.gemm_ws; }
@@ -426,7 +466,8 @@ int dec_bwd_step(const Bwd& c, int t) {
     st.site_h = T2_SITE_DEC_H; st.site_c = T2_SITE_DEC_C;
     st.idx_base = (uint32_t)(c.R(t) * z.Hd); st.idx_bstride = (uint32_t)z.Hd;
     if (c.use16) st.dg16 = c.S16(c.BL.dg16d);
-    { ProfScope ps(PK_LSTM_DEC_BWD_PW, c.s); T2_TRY(lstm_bwd_pointwise(p, c.s)); }
+    hipStream_t sd = c.sd ? c.sd : c.s;
+    { ProfScope ps(PK_LSTM_DEC_BWD_PW, sd); T2_TRY(lstm_bwd_pointwise(p, sd)); }
     if (t == 0) return 0;
     LstmBwdGemmDesc g{};
     g.nstreams = 1; g.B = z.B; g.H4 = 4 * z.Hd; g.KS = ks; g.NC = z.Hd;
@@ -434,8 +475,8 @@ int dec_bwd_step(const Bwd& c, int t) {
     g.st[0].seg[0] = LstmBwdSeg{c.w.dec.w_hh, (long)z.Hd, z.Hd}; g.st[0].nseg = 1;
     g.st[0].part = c.S(c.BL.partd);
     if (c.use16) { g.st[0].dg16 = c.S16(c.BL.dg16d); g.st[0].wt16 = c.W16(c.L.wt16d); }
-    ProfScope ps(PK_LSTM_DEC_BWD_GEMM, c.s);
-    return lstm_bwd_gemm(g, c.s);
+    ProfScope ps(PK_LSTM_DEC_BWD_GEMM, sd);
+    return lstm_bwd_gemm(g, sd);
 }
 
 int att_bwd_step(const Bwd& c, int t) {
@@ -531,6 +572,7 @@ int t2_set_precision(int mode) {
     return 0;
 }
 int t2_get_precision(void) { return get_precision(); }
+int t2_set_overlap(int on) { g_overlap = on != 0; return 0; }
 
 int t2_decoder_layout_query(const t2_dims* dims, int B, int T, int Tin, int Tsub, t2_decoder_layout* out) {
     T2_REQUIRE(dims && out, "null argument");
@@ -567,19 +609,30 @@ int t2_decoder_forward(const t2_dims* dims, const t2_decoder_weights* w, const t
         g.bias1 = lw.b_ih; g.bias2 = lw.b_hh;
         T2_TRY(gemm(g, c.s));
     }
-    // serial loop A: attention LSTMs + attention (the only truly recurrent chain through the contexts)
-    for (int t = 0; t < z.T; ++t) {
-        T2_TRY(att_lstm_step(c, t));
-        T2_TRY(attention_step(c, t));
-    }
-    // hoisted input half of the decoder LSTM over all frames:  [att_h|ctx|att_h_sub|ctx_sub] . W_ih^T + b
-    {
-        GemmDesc g = linear(c.P(L.din), z.WD, w->dec.w_ih, z.WD, c.P(L.pred), 4 * z.Hd, BT, 4 * z.Hd, z.WD);
+    // Two serial chains, overlapped in chunks of steps:
+    //   A (caller's stream): attention LSTMs + attention — the only truly recurrent chain through the contexts
+    //   B (side stream):     hoisted input half of the decoder LSTM for the chunk A just finished
+    //                        ([att_h|ctx|att_h_sub|ctx_sub] . W_ih^T + b), then the decoder-LSTM recurrence over it
+    Side* side = nullptr;
+    const bool overlap = g_overlap && z.T >= 32;
+    if (overlap) { T2_TRY(side_get(&side)); c.sd = side->s; }
+    const int CH = overlap ? std::max(16, (z.T + 7) / 8) : z.T;
+    size_t ne = 0;
+    for (int t0 = 0; t0 < z.T; t0 += CH) {
+        const int t1 = std::min(z.T, t0 + CH);
+        for (int t = t0; t < t1; ++t) {
+            T2_TRY(att_lstm_step(c, t));
+            T2_TRY(attention_step(c, t));
+        }
+        hipStream_t sb = overlap ? side->s : c.s;
+        if (overlap) T2_TRY(stream_edge(*side, ne++, c.s, sb));
+        GemmDesc g = linear(c.P(L.din) + c.R(t0) * z.WD, z.WD, w->dec.w_ih, z.WD, c.P(L.pred) + c.R(t0) * 4 * z.Hd, 4 * z.Hd,
+                            (t1 - t0) * z.B, 4 * z.Hd, z.WD);
         g.bias1 = w->dec.b_ih; g.bias2 = w->dec.b_hh;
-        T2_TRY(gemm(g, c.s));
+        T2_TRY(gemm(g, sb));
+        for (int t = t0; t < t1; ++t) T2_TRY(dec_lstm_step(c, t));
     }
-    // serial loop B: decoder LSTM recurrence
-    for (int t = 0; t < z.T; ++t) T2_TRY(dec_lstm_step(c, t));
+    if (overlap) T2_TRY(stream_edge(*side, ne++, side->s, c.s));         // join
     // projections over all frames
     return projection(c, c.P(L.dout), z.WO, BT, a->mel_out, z.M, a->gate_out, 1, true);
 }
@@ -621,20 +674,36 @@ int t2_decoder_backward(const t2_dims* dims, const t2_decoder_weights* w, const 
         T2_TRY(colsum(dmel, z.M, BT, z.M, g->proj_b, nullptr, cws, c.s));
         T2_TRY(colsum(dgate, 1, BT, 1, g->gate_b, nullptr, cws, c.s));
     }
-    // ---- decoder LSTM, reverse time
-    for (int t = z.T - 1; t >= 0; --t) T2_TRY(dec_bwd_step(c, t));
+    // ---- two reverse-time chains, overlapped in chunks of steps (see Side above):
+    //   B (side stream):     decoder-LSTM BPTT of a chunk, then dDIN rows of the chunk = dG . W_ih
+    //   A (caller's stream): attention-LSTM + attention BPTT of the chunk B finished
+    Side* side = nullptr;
+    const bool overlap = g_overlap && z.T >= 32;
+    size_t ne = 0;
+    if (overlap) {
+        T2_TRY(side_get(&side)); c.sd = side->s;
+        T2_TRY(stream_edge(*side, ne++, c.s, side->s));                 // fork: dDOUT is complete
+    }
+    const int CH = overlap ? std::max(16, (z.T + 7) / 8) : z.T;
+    const float* DGd = c.S(BL.dgd);
+    for (int t1 = z.T; t1 > 0; t1 -= CH) {
+        const int t0 = std::max(0, t1 - CH);
+        hipStream_t sb = overlap ? side->s : c.s;
+        for (int t = t1 - 1; t >= t0; --t) T2_TRY(dec_bwd_step(c, t));
+        T2_TRY(gemm(matmul_nn(DGd + c.R(t0) * 4 * z.Hd, 4 * z.Hd, w->dec.w_ih, z.WD, c.S(BL.ddin) + c.R(t0) * z.WD, z.WD,
+                              (t1 - t0) * z.B, z.WD, 4 * z.Hd), sb));
+        if (overlap) T2_TRY(stream_edge(*side, ne++, sb, c.s));
+        for (int t = t1 - 1; t >= t0; --t) T2_TRY(att_bwd_step(c, t));
+    }
     {
-        const float* DG = c.S(BL.dgd);
-        // input half: dDIN = dG . W_ih ; dW_ih = dG^T . DIN ; recurrent half: dW_hh = dG^T . dec_h(t-1)
-        T2_TRY(gemm(matmul_nn(DG, 4 * z.Hd, w->dec.w_ih, z.WD, c.S(BL.ddin), z.WD, BT, z.WD, 4 * z.Hd), c.s));
+        const float* DG = DGd;
+        // dW_ih = dG^T . DIN ; recurrent half: dW_hh = dG^T . dec_h(t-1)
         T2_TRY(gemm(matmul_tn(c, DG, 4 * z.Hd, c.W(L.din), z.WD, g->dec.w_ih, z.WD, 4 * z.Hd, z.WD, BT), c.s));
         // h(t-1) pairs with dG(t): drop the first step's rows of dG and the last step's rows of dec_h
         if (z.T > 1) T2_TRY(gemm(matmul_tn(c, DG + (long)z.B * 4 * z.Hd, 4 * z.Hd, c.W(L.dout), z.WO, g->dec.w_hh, z.Hd, 4 * z.Hd, z.Hd, BT - z.B), c.s));
         else T2_TRY(fill_f32(g->dec.w_hh, 0.f, (size_t)4 * z.Hd * z.Hd, c.s));
         T2_TRY(colsum(DG, 4 * z.Hd, BT, 4 * z.Hd, g->dec.b_ih, g->dec.b_hh, cws, c.s));
     }
-    // ---- attention LSTMs + attention, reverse time
-    for (int t = z.T - 1; t >= 0; --t) T2_TRY(att_bwd_step(c, t));
     for (int s = 0; s < z.NS; ++s) {
         const t2_lstm_weights& lw = s ? w->att_sub : w->att;
         const t2_lstm_grads& lg = s ? g->att_sub : g->att;
@@ -920,7 +989,7 @@ int t2_prof_collect(int n_kinds, double* total_ms_host, int* launches_host) {
     g_prof.on = false;
     for (int i = 0; i < n_kinds; ++i) { total_ms_host[i] = 0.0; launches_host[i] = 0; }
     if (g_prof.used == 0) return 0;
-    T2_CHECK_HIP(hipEventSynchronize(g_prof.ev[g_prof.used - 1]));
+    T2_CHECK_HIP(hipDeviceSynchronize());                // events live on two streams
     for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
         float ms = 0.f;
         T2_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]));

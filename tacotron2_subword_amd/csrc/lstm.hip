@@ -57,7 +57,8 @@ template <int MT, int BKT> struct Tile {
     static constexpr int BB_FLOATS = BKT * PBN;
     static constexpr int QA = MT * 32 * (BKT / 4) / NTH;       // float4 per thread, A tile
     static constexpr int QB = 32 * (BKT / 4) / NTH;            // float4 per thread, B tile (either layout)
-    static constexpr int FWD_FLOATS = (A_FLOATS + BF_FLOATS > NW * 32 * PP ? A_FLOATS + BF_FLOATS : NW * 32 * PP);
+    static constexpr int PART_FLOATS = (MT >= 2 ? 2 : 1) * NW * 32 * PP;      // the tail sums two batch tiles at a time
+    static constexpr int FWD_FLOATS = (A_FLOATS + BF_FLOATS > PART_FLOATS ? A_FLOATS + BF_FLOATS : PART_FLOATS);
     static constexpr int BWD_FLOATS = (A_FLOATS + BB_FLOATS > NW * 32 * PP ? A_FLOATS + BB_FLOATS : NW * 32 * PP);
 };
 
@@ -127,66 +128,100 @@ __device__ __forceinline__ void compute_stage_bwd(const float* __restrict__ As, 
     }
 }
 
+// Pointwise operands that do not depend on the GEMM — pre-activations (+ biases), previous cell state and this
+// unit group's slice of the query projection W_q — are requested right after the first operand stage so that their
+// (cold, HBM) latency hides under the K loop.  Thread (mi, bl, uu) serves batch row (gi*G + mi)*32 + bl, unit u0 + uu
+// of group gi (G = 2 batch tiles are finished per pass by the 512 threads).
+template <int MT> struct TailRegs {
+    static constexpr int G = MT >= 2 ? 2 : 1, NG = (MT + G - 1) / G;
+    float pre[NG][4]; float cp[NG]; float wq[4];
+};
+template <int MT>
+__device__ __forceinline__ void tail_prefetch(const LstmStepDesc& d, const LstmStream& st, int u0, TailRegs<MT>& tr) {
+    constexpr int G = TailRegs<MT>::G, NG = TailRegs<MT>::NG;
+    const int B = d.B, H = d.H;
+    const int mi = threadIdx.x >> 8, bl = (threadIdx.x & 255) >> 3, u = u0 + (threadIdx.x & 7);
+    if (mi < G) {
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const int b = min((gi * G + mi) * 32 + bl, B - 1);            // clamped: rows >= B are never consumed
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v = 0.f;
+                if (st.pre) v += st.pre[(long)b * st.ldpre + g * H + u];      // wave-uniform conditions
+                if (st.bias1) v += st.bias1[g * H + u];
+                if (st.bias2) v += st.bias2[g * H + u];
+                tr.pre[gi][g] = v;
+            }
+            tr.cp[gi] = st.c_prev ? st.c_prev[(long)b * st.ldc_prev + u] : 0.f;
+        }
+    }
+    if (st.wq) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = min((int)threadIdx.x + k * NTH, st.A * HU - 1);
+            tr.wq[k] = st.wq[(long)(i / HU) * H + u0 + (i % HU)];
+        }
+    }
+}
+
 // Everything after the K loop, shared by the fp32- and bf16-operand step kernels: sum the NW partial
 // tiles in fixed order, gates, cell update, dropout, stores, optional query-projection partials.
-template <int MT, bool kPrefetch>
+template <int MT>
 __device__ __forceinline__ void lstm_tail(const LstmStepDesc& d, const LstmStream& st, int u0, int wave, int r, int hk,
-                                          f32x16 (&acc)[MT], float* __restrict__ part, float* __restrict__ hs,
-                                          const float (&pre_v)[kPrefetch ? MT : 1][4], const float (&cp_v)[kPrefetch ? MT : 1]) {
+                                          f32x16 (&acc)[MT], float* __restrict__ part, float* __restrict__ hs, const TailRegs<MT>& tr) {
+    constexpr int G = TailRegs<MT>::G, NG = TailRegs<MT>::NG;
     const int B = d.B, H = d.H;
     const RngKey kh = rng_key(d.seed, st.site_h), kc = rng_key(d.seed, st.site_c);
     const float scale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
+    const int mi = threadIdx.x >> 8, bl = (threadIdx.x & 255) >> 3, uu = threadIdx.x & 7;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        if (m > 0) __syncthreads();
+    for (int gi = 0; gi < NG; ++gi) {
+        if (gi > 0) __syncthreads();
         // lane holds column r, rows (e&3) + 8*(e>>2) + 4*hk
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-            part[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk) * PP + r] = acc[m][e];
-        __syncthreads();
-        if (threadIdx.x < 32 * HU) {
-            const int bl = threadIdx.x >> 3, uu = threadIdx.x & 7;
-            const int b = m * 32 + bl, u = u0 + uu;
-            if (b < B) {
-                float g4[4];
+        for (int q = 0; q < G; ++q) {
+            if (gi * G + q < MT) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float sum = 0.f;
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) sum += part[(w * 32 + bl) * PP + g * 8 + uu];
-                    if (kPrefetch) {
-                        sum += pre_v[kPrefetch ? m : 0][g];
-                    } else {
-                        if (st.pre) sum += st.pre[(long)b * st.ldpre + g * H + u];
-                        if (st.bias1) sum += st.bias1[g * H + u];
-                        if (st.bias2) sum += st.bias2[g * H + u];
-                    }
-                    g4[g] = sum;
-                }
-                const bool active = !st.lengths || st.t < st.lengths[b];
-                float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]), og = sigmoidf_(g4[3]);
-                const float cp = kPrefetch ? cp_v[kPrefetch ? m : 0] : (st.c_prev ? st.c_prev[(long)b * st.ldc_prev + u] : 0.f);
-                float cn = fg * cp + ig * gg;
-                float hn = og * tanhf(cn);
-                if (!active) { ig = fg = gg = og = 0.f; cn = 0.f; hn = 0.f; }
-                if (st.gates) {
-                    float* gp = st.gates + (long)b * st.ldgates + u;
-                    gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
-                }
-                if (st.c_new) st.c_new[(long)b * st.ldc_new + u] = cn;
-                float ho = hn, co = cn;
-                if (d.drop_p > 0.f) {
-                    const uint32_t idx = st.idx_base + (uint32_t)b * st.idx_bstride + (uint32_t)u;
-                    ho = rng_keep(kh, idx, d.drop_p) ? hn * scale : 0.f;
-                    co = rng_keep(kc, idx, d.drop_p) ? cn * scale : 0.f;
-                }
-                st.h_out[(long)b * st.ldh_out + u] = ho;
-                if (st.h_out2) st.h_out2[(long)b * st.ldh_out2 + u] = ho;
-                st.c_out[(long)b * st.ldc_out + u] = co;
-                if (st.h16_out) st.h16_out[(long)b * st.ldh16 + u] = (__bf16)ho;
-                if (st.h16_out2) st.h16_out2[(long)b * st.ldh16_2 + u] = (__bf16)ho;
-                hs[b * HU + uu] = ho;
+                for (int e = 0; e < 16; ++e)
+                    part[((q * NW + wave) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk) * PP + r] = acc[gi * G + q < MT ? gi * G + q : 0][e];
             }
+        }
+        __syncthreads();
+        const int m = gi * G + mi;
+        const int b = m * 32 + bl, u = u0 + uu;
+        if (mi < G && m < MT && b < B) {
+            const float* pt = part + mi * NW * 32 * PP;
+            float g4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sum += pt[(w * 32 + bl) * PP + g * 8 + uu];
+                g4[g] = sum + tr.pre[gi][g];
+            }
+            const bool active = !st.lengths || st.t < st.lengths[b];
+            float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]), og = sigmoidf_(g4[3]);
+            float cn = fg * tr.cp[gi] + ig * gg;
+            float hn = og * tanhf(cn);
+            if (!active) { ig = fg = gg = og = 0.f; cn = 0.f; hn = 0.f; }
+            if (st.gates) {
+                float* gp = st.gates + (long)b * st.ldgates + u;
+                gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
+            }
+            if (st.c_new) st.c_new[(long)b * st.ldc_new + u] = cn;
+            float ho = hn, co = cn;
+            if (d.drop_p > 0.f) {
+                const uint32_t idx = st.idx_base + (uint32_t)b * st.idx_bstride + (uint32_t)u;
+                ho = rng_keep(kh, idx, d.drop_p) ? hn * scale : 0.f;
+                co = rng_keep(kc, idx, d.drop_p) ? cn * scale : 0.f;
+            }
+            st.h_out[(long)b * st.ldh_out + u] = ho;
+            if (st.h_out2) st.h_out2[(long)b * st.ldh_out2 + u] = ho;
+            st.c_out[(long)b * st.ldc_out + u] = co;
+            if (st.h16_out) st.h16_out[(long)b * st.ldh16 + u] = (__bf16)ho;
+            if (st.h16_out2) st.h16_out2[(long)b * st.ldh16_2 + u] = (__bf16)ho;
+            hs[b * HU + uu] = ho;
         }
     }
 
@@ -196,14 +231,18 @@ __device__ __forceinline__ void lstm_tail(const LstmStepDesc& d, const LstmStrea
         __syncthreads();
         float* wqs = part;                            // [A][HU]
         const int A = st.A;
-        for (int i = threadIdx.x; i < A * HU; i += NTH) wqs[i] = st.wq[(long)(i / HU) * H + u0 + (i % HU)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + k * NTH;
+            if (i < A * HU) wqs[i] = tr.wq[k];
+        }
         __syncthreads();
         float* qp = st.qpart + (long)blockIdx.x * B * A;
         for (int i = threadIdx.x; i < B * A; i += NTH) {
             const int b = i / A, a = i % A;
             float sum = 0.f;
 #pragma unroll
-            for (int uu = 0; uu < HU; ++uu) sum += hs[b * HU + uu] * wqs[a * HU + uu];
+            for (int uu2 = 0; uu2 < HU; ++uu2) sum += hs[b * HU + uu2] * wqs[a * HU + uu2];
             qp[i] = sum;
         }
     }
@@ -245,28 +284,10 @@ __global__ __launch_bounds__(NTH) void lstm_step_fwd_kernel(LstmStepDesc d) {
         if (kin >= sg.k) { kin = 0; ++seg; }
     };
     if (nstages > 0) load_next();
-    // The pointwise tail needs pre[b, g*H+u] (streamed once from HBM) and c_prev: request them now so
-    // that their latency hides under the GEMM — but AFTER the first stage's operands (vector-memory
-    // operations complete in order: stage 0 must not queue behind these cold reads).
-    constexpr bool kPrefetch = MT <= 4;
-    float pre_v[kPrefetch ? MT : 1][4];
-    float cp_v[kPrefetch ? MT : 1];
-    if (kPrefetch && threadIdx.x < 32 * HU) {
-        const int bl = threadIdx.x >> 3, u = u0 + (threadIdx.x & 7);
-#pragma unroll
-        for (int m = 0; m < (kPrefetch ? MT : 1); ++m) {
-            const int b = min(m * 32 + bl, B - 1);            // clamped: rows >= B are never consumed
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v = 0.f;
-                if (st.pre) v += st.pre[(long)b * st.ldpre + g * H + u];          // wave-uniform conditions
-                if (st.bias1) v += st.bias1[g * H + u];
-                if (st.bias2) v += st.bias2[g * H + u];
-                pre_v[m][g] = v;
-            }
-            cp_v[m] = st.c_prev ? st.c_prev[(long)b * st.ldc_prev + u] : 0.f;
-        }
-    }
+    // request the tail's operands now — but AFTER the first stage's operands (vector-memory operations complete
+    // in order: stage 0 must not queue behind these cold reads)
+    TailRegs<MT> tr;
+    tail_prefetch<MT>(d, st, u0, tr);
 
     if (nstages > 0) {
         store_rows<BKT, TL::QA>(As, ra);
@@ -287,7 +308,7 @@ __global__ __launch_bounds__(NTH) void lstm_step_fwd_kernel(LstmStepDesc d) {
     }
 
     T2_STAMP(2);
-    lstm_tail<MT, kPrefetch>(d, st, u0, wave, r, hk, acc, part, hs, pre_v, cp_v);
+    lstm_tail<MT>(d, st, u0, wave, r, hk, acc, part, hs, tr);
     T2_STAMP(4);
 }
 
@@ -305,7 +326,8 @@ template <int MT, int BKT> struct Tile16 {
     static constexpr int A_ELEMS = MT * 32 * P, B_ELEMS = 32 * P;
     static constexpr int QA = MT * 32 * (BKT / 8) / NTH, QB = 32 * (BKT / 8) / NTH;
     static constexpr int STAGE_FLOATS = (A_ELEMS + B_ELEMS + 1) / 2;
-    static constexpr int SMEM_FLOATS = (STAGE_FLOATS > NW * 32 * PP ? STAGE_FLOATS : NW * 32 * PP);
+    static constexpr int PART_FLOATS = (MT >= 2 ? 2 : 1) * NW * 32 * PP;
+    static constexpr int SMEM_FLOATS = (STAGE_FLOATS > PART_FLOATS ? STAGE_FLOATS : PART_FLOATS);
 };
 
 template <int BKT, int Q, typename RowPtr>
@@ -396,25 +418,8 @@ __global__ __launch_bounds__(NTH) void lstm_step_fwd_bf16_kernel(LstmStepDesc d)
     };
     if (nstages > 0) load_stage(0, ra0, rb0);
     if (nstages > 1) load_stage(1, ra1, rb1);
-    constexpr bool kPrefetch = true;
-    float pre_v[MT][4];
-    float cp_v[MT];
-    if (threadIdx.x < 32 * HU) {
-        const int bl = threadIdx.x >> 3, u = u0 + (threadIdx.x & 7);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int b = min(m * 32 + bl, B - 1);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v = 0.f;
-                if (st.pre) v += st.pre[(long)b * st.ldpre + g * H + u];
-                if (st.bias1) v += st.bias1[g * H + u];
-                if (st.bias2) v += st.bias2[g * H + u];
-                pre_v[m][g] = v;
-            }
-            cp_v[m] = st.c_prev ? st.c_prev[(long)b * st.ldc_prev + u] : 0.f;
-        }
-    }
+    TailRegs<MT> tr;
+    tail_prefetch<MT>(d, st, u0, tr);
     if (nstages > 0) { store_rows16<BKT, TL::QA>(As, ra0); store_rows16<BKT, TL::QB>(Bs, rb0); }
     __syncthreads();
     T2_STAMP(1);
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(NTH) void lstm_step_fwd_bf16_kernel(LstmStepDesc d)
         }
     }
     T2_STAMP(2);
-    lstm_tail<MT, kPrefetch>(d, st, u0, wave, r, hk, acc, part, hs, pre_v, cp_v);
+    lstm_tail<MT>(d, st, u0, wave, r, hk, acc, part, hs, tr);
     T2_STAMP(4);
 }
 

@@ -38,15 +38,18 @@ def hip_rnd(ops, L, hp, seed, B, T, Tin, Tsub):
                 sma_noise_bert=ops.rng_normal(seed, S["NOISE_SUB"], B * T * Tsub).view(T, B, Tsub).cpu())
 
 
-@pytest.mark.parametrize("cfg", ["tiny_eval", "tiny_train", "tiny_b33", "tiny_long", "default_train", "default_align"])
+@pytest.mark.parametrize("cfg", ["tiny_eval", "tiny_train", "tiny_b33", "tiny_long", "tiny_T40", "default_train", "default_align"])
 @pytest.mark.parametrize("att", [SMA, LSA])
 def test_decoder_backward_vs_autograd(env, cfg, att):
     L, ops = env
-    training = cfg in ("tiny_train", "default_train", "default_align", "tiny_b33", "tiny_long")
+    training = cfg in ("tiny_train", "default_train", "default_align", "tiny_b33", "tiny_long", "tiny_T40")
     with_align = cfg in ("default_align", "tiny_b33", "tiny_long")
     if cfg == "tiny_long":                       # several 32-position chunks per attention step, ragged tails
         hp = tiny_hp(att)
         B, Tin, Tsub, T = 2, 70, 37, 6
+    elif cfg == "tiny_T40":                      # long enough for the chunked two-stream schedule (3 chunks of 16 steps)
+        hp = tiny_hp(att)
+        B, Tin, Tsub, T = 3, 12, 9, 40
     elif cfg.startswith("tiny"):
         hp = tiny_hp(att)
         B, Tin, Tsub, T = (33 if cfg == "tiny_b33" else 5), 11, 7, 9
@@ -111,3 +114,33 @@ def test_decoder_backward_vs_autograd(env, cfg, att):
         if not err < tol:
             bad[k] = (err, tol)
     assert not bad, bad
+
+
+def test_two_stream_schedule_is_bitwise_identical(env):
+    """The side-stream schedule only reorders independent launches: outputs and gradients equal the one-stream run bit for bit."""
+    L, ops = env
+    hp = tiny_hp(SMA)
+    B, Tin, Tsub, T = 4, 12, 9, 50
+    P = recipe.make_weights(hp, seed=5)
+    x, y = recipe.parse_batch(recipe.make_batch(hp, B, Tin, Tsub, T, seed=B))
+    mem, mem_sub = oracle_memories(P, hp, x)
+    dims = L.dims_from_hparams(hp)
+    Pd = to_dev(P)
+    W = L.decoder_weights(Pd, dims.attention_kind)
+    memd, memsd = mem.cuda().contiguous(), mem_sub.cuda().contiguous()
+    g = torch.Generator().manual_seed(3)
+    R_mel, R_gate = torch.randn(B, T, hp["n_mel_channels"], generator=g).cuda(), torch.randn(B, T, generator=g).cuda()
+    res = []
+    for on in (1, 0, 1):
+        L.check(L.lib().t2_set_overlap(on))
+        dp = ops.decoder_forward(W, dims, memd, memsd, x[1].cuda(), x[2].cuda(), x[3].cuda().contiguous(),
+                                 training=True, prenet_dropout=True, seed=7)
+        G, dmem, dmems = ops.decoder_backward(W, Pd, dims, dp, memd, memsd, R_mel, R_gate, training=True, prenet_dropout=True, seed=7)
+        torch.cuda.synchronize()
+        res.append((dp.mel.clone(), dp.gate.clone(), dmem.clone(), dmems.clone(), {k: v.clone() for k, v in G.items()}))
+    L.check(L.lib().t2_set_overlap(1))
+    for other in res[1:]:
+        for a, b in zip(res[0][:4], other[:4]):
+            assert torch.equal(a, b)
+        for k in res[0][4]:
+            assert torch.equal(res[0][4][k], other[4][k]), k
