@@ -19,7 +19,12 @@ ap.add_argument("--Tin", type=int, default=100)
 ap.add_argument("--Tsub", type=int, default=60)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--bwd", type=int, default=1)
+ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--overlap", type=int, default=1)
+ap.add_argument("--prof", type=int, default=1, help="print per-kernel HIP-event averages of one extra pass")
 a = ap.parse_args()
+L.set_precision(a.dtype)
+L.check(L.lib().t2_set_overlap(a.overlap))
 hp = hp_for(SMA)
 P = to_dev(recipe.make_weights(hp))
 dims = L.dims_from_hparams(hp)
@@ -43,3 +48,11 @@ for it in range(a.iters):
     print(f"iter {it}: fwd {1e3*(t1-t0):.2f} ms  bwd {1e3*(t2-t1):.2f} ms  frames/s fwd+bwd {a.B*a.T/(t2-t0):.0f}", flush=True)
     del dp
 print("finite:", bool(torch.isfinite(dm).all()) if a.bwd else True)
+if a.prof:
+    L.prof_enable(8 * a.T + 64)
+    dp = ops.decoder_forward(W, dims, mem, mems, tl, bl, mels, training=True, prenet_dropout=True, seed=99)
+    if a.bwd:
+        ops.decoder_backward(W, P, dims, dp, mem, mems, dmel, dgate, training=True, prenet_dropout=True, seed=99)
+    for k, (ms, n) in L.prof_collect().items():
+        if n:
+            print(f"  {k:26s} {n:5d} launches  avg {1e3 * ms / n:7.2f} us  total {ms:7.2f} ms")

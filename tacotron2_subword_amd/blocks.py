@@ -21,11 +21,13 @@ _WS = {}
 
 
 def _scratch(dev, n_floats: int) -> torch.Tensor:
-    """Grow-only scratch buffer per device (kernels on one stream run in order, so reuse is safe)."""
-    t = _WS.get(dev)
+    """Grow-only scratch buffer per (device, stream): kernels on one stream run in order, so reuse within a stream
+    is safe; the two front ends run on different streams (model.BERT_Tacotron2._fronts) and must not share one."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
+    t = _WS.get(key)
     if t is None or t.numel() < n_floats:
         t = torch.empty(int(n_floats * 1.25) + 1024, dtype=torch.float32, device=dev)
-        _WS[dev] = t
+        _WS[key] = t
     return t
 
 

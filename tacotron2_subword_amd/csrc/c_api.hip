@@ -693,17 +693,20 @@ int t2_decoder_backward(const t2_dims* dims, const t2_decoder_weights* w, const 
         T2_TRY(gemm(matmul_nn(DGd + c.R(t0) * 4 * z.Hd, 4 * z.Hd, w->dec.w_ih, z.WD, c.S(BL.ddin) + c.R(t0) * z.WD, z.WD,
                               (t1 - t0) * z.B, z.WD, 4 * z.Hd), sb));
         if (overlap) T2_TRY(stream_edge(*side, ne++, sb, c.s));
+        if (t0 == 0) {
+            // the decoder LSTM's weight gradients need nothing from chain A: they run on chain B's stream once its
+            // recurrence is done, underneath the rest of chain A (whose launches leave most CUs idle)
+            const float* DG = DGd;
+            // dW_ih = dG^T . DIN ; recurrent half: dW_hh = dG^T . dec_h(t-1)
+            T2_TRY(gemm(matmul_tn(c, DG, 4 * z.Hd, c.W(L.din), z.WD, g->dec.w_ih, z.WD, 4 * z.Hd, z.WD, BT), sb));
+            // h(t-1) pairs with dG(t): drop the first step's rows of dG and the last step's rows of dec_h
+            if (z.T > 1) T2_TRY(gemm(matmul_tn(c, DG + (long)z.B * 4 * z.Hd, 4 * z.Hd, c.W(L.dout), z.WO, g->dec.w_hh, z.Hd, 4 * z.Hd, z.Hd, BT - z.B), sb));
+            else T2_TRY(fill_f32(g->dec.w_hh, 0.f, (size_t)4 * z.Hd * z.Hd, sb));
+            T2_TRY(colsum(DG, 4 * z.Hd, BT, 4 * z.Hd, g->dec.b_ih, g->dec.b_hh, cws, sb));
+        }
         for (int t = t1 - 1; t >= t0; --t) T2_TRY(att_bwd_step(c, t));
     }
-    {
-        const float* DG = DGd;
-        // dW_ih = dG^T . DIN ; recurrent half: dW_hh = dG^T . dec_h(t-1)
-        T2_TRY(gemm(matmul_tn(c, DG, 4 * z.Hd, c.W(L.din), z.WD, g->dec.w_ih, z.WD, 4 * z.Hd, z.WD, BT), c.s));
-        // h(t-1) pairs with dG(t): drop the first step's rows of dG and the last step's rows of dec_h
-        if (z.T > 1) T2_TRY(gemm(matmul_tn(c, DG + (long)z.B * 4 * z.Hd, 4 * z.Hd, c.W(L.dout), z.WO, g->dec.w_hh, z.Hd, 4 * z.Hd, z.Hd, BT - z.B), c.s));
-        else T2_TRY(fill_f32(g->dec.w_hh, 0.f, (size_t)4 * z.Hd * z.Hd, c.s));
-        T2_TRY(colsum(DG, 4 * z.Hd, BT, 4 * z.Hd, g->dec.b_ih, g->dec.b_hh, cws, c.s));
-    }
+    if (overlap) T2_TRY(stream_edge(*side, ne++, side->s, c.s));       // join (split-K scratch and colsum scratch are shared)
     for (int s = 0; s < z.NS; ++s) {
         const t2_lstm_weights& lw = s ? w->att_sub : w->att;
         const t2_lstm_grads& lg = s ? g->att_sub : g->att;

@@ -495,8 +495,10 @@ int gemm(const GemmDesc& din, hipStream_t s) {
         if (splitk <= 0) {
             const long tiles = (long)tm * tn * d.batch;
             splitk = 1;
-            if (tiles < 256 && kch >= 64) {
-                splitk = (int)((512 + tiles - 1) / tiles);
+            // fewer than two tile-waves over the 256 CUs and a long K: split so that every CU holds several workgroups
+            // (a lone 128x128 workgroup per CU cannot cover its own operand latency)
+            if (tiles < 512 && kch >= 64) {
+                splitk = (int)((1024 + tiles - 1) / tiles);
                 if (splitk > kch / 16) splitk = kch / 16;
             }
         }

@@ -448,12 +448,32 @@ __global__ __launch_bounds__(NTH) void lstm_step_fwd_bf16_kernel(LstmStepDesc d)
 //   d(pre-activations) = { dcn*g*i(1-i), dcn*c_prev*f(1-f), dcn*i*(1-g^2), dhn*tanh(cn)*o(1-o) }
 //   dc_state <- dcn * f                                                    gradient on c_out(t-1)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(LstmBwdPointDesc d) {
-    const LstmBwdStream& st = d.st[blockIdx.y];
-    const int B = d.B, H = d.H;
-    const long i = blockIdx.x * 256l + threadIdx.x;
-    if (i >= (long)B * H) return;
-    const int b = (int)(i / H), u = (int)(i % H);
+// shared pointwise math of the two kernels below
+struct PwIn { float dh, dc, ig, fg, gg, og, cn, cp; };
+__device__ __forceinline__ void lstm_bwd_point(const LstmBwdPointDesc& d, const LstmBwdStream& st, int b, int u, PwIn in) {
+    const int H = d.H;
+    float dh = in.dh, dc = in.dc;
+    if (d.drop_p > 0.f) {
+        const uint32_t idx = st.idx_base + (uint32_t)b * st.idx_bstride + (uint32_t)u;
+        const float scale = 1.0f / (1.0f - d.drop_p);
+        dh = rng_keep(rng_key(d.seed, st.site_h), idx, d.drop_p) ? dh * scale : 0.f;
+        dc = rng_keep(rng_key(d.seed, st.site_c), idx, d.drop_p) ? dc * scale : 0.f;
+    }
+    const float tc = tanhf(in.cn);
+    const float dcn = dc + dh * in.og * (1.0f - tc * tc);
+    const float d0 = dcn * in.gg * in.ig * (1.0f - in.ig), d1 = dcn * in.cp * in.fg * (1.0f - in.fg);
+    const float d2 = dcn * in.ig * (1.0f - in.gg * in.gg), d3 = dh * tc * in.og * (1.0f - in.og);
+    float* dg = st.dg + (long)b * st.lddg + u;
+    dg[0] = d0; dg[H] = d1; dg[2 * H] = d2; dg[3 * H] = d3;
+    if (st.dg16) {                                   // bf16 copy for the bf16-operand recurrent GEMM of this step
+        __bf16* g16 = st.dg16 + (long)b * 4 * H + u;
+        g16[0] = (__bf16)d0; g16[H] = (__bf16)d1; g16[2 * H] = (__bf16)d2; g16[3 * H] = (__bf16)d3;
+    }
+    st.dc_state[(long)b * H + u] = dcn * in.fg;
+}
+__device__ __forceinline__ PwIn lstm_bwd_load(const LstmBwdPointDesc& d, const LstmBwdStream& st, int b, int u) {
+    const int H = d.H;
+    PwIn in;
     float dh = 0.f;
     if (st.dh1) dh += st.dh1[(long)b * st.lddh1 + u];
     if (st.dh2) dh += st.dh2[(long)b * st.lddh2 + u];
@@ -467,37 +487,64 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(LstmBwdPointDes
         for (int z = 0; z < 8; ++z) acc += pv[z];
         dh += acc;
     }
-    if (st.dq) {
-        const float* q = st.dq + (long)b * st.lddq;
-        const float* w = st.wq + u;
-        float acc = 0.f;
-#pragma unroll 16
-        for (int a = 0; a < st.A; ++a) acc += q[a] * w[(long)a * H];
-        dh += acc;
-    }
-    float dc = d.first ? 0.f : st.dc_state[i];
-    if (d.drop_p > 0.f) {
-        const uint32_t idx = st.idx_base + (uint32_t)b * st.idx_bstride + (uint32_t)u;
-        const float scale = 1.0f / (1.0f - d.drop_p);
-        dh = rng_keep(rng_key(d.seed, st.site_h), idx, d.drop_p) ? dh * scale : 0.f;
-        dc = rng_keep(rng_key(d.seed, st.site_c), idx, d.drop_p) ? dc * scale : 0.f;
-    }
+    in.dh = dh;
+    in.dc = d.first ? 0.f : st.dc_state[(long)b * H + u];
     const float* gp = st.gates + (long)b * st.ldgates + u;
-    const float ig = gp[0], fg = gp[H], gg = gp[2 * H], og = gp[3 * H];
-    const float cn = st.c_new[(long)b * st.ldc_new + u];
-    const float cp = st.c_prev ? st.c_prev[(long)b * st.ldc_prev + u] : 0.f;
-    const float tc = tanhf(cn);
-    const float dcn = dc + dh * og * (1.0f - tc * tc);
-    float* dg = st.dg + (long)b * st.lddg + u;
-    dg[0] = dcn * gg * ig * (1.0f - ig);
-    dg[H] = dcn * cp * fg * (1.0f - fg);
-    dg[2 * H] = dcn * ig * (1.0f - gg * gg);
-    dg[3 * H] = dh * tc * og * (1.0f - og);
-    if (st.dg16) {                                   // bf16 copy for the bf16-operand recurrent GEMM of this step
-        __bf16* g16 = st.dg16 + (long)b * 4 * H + u;
-        g16[0] = (__bf16)dg[0]; g16[H] = (__bf16)dg[H]; g16[2 * H] = (__bf16)dg[2 * H]; g16[3 * H] = (__bf16)dg[3 * H];
+    in.ig = gp[0]; in.fg = gp[H]; in.gg = gp[2 * H]; in.og = gp[3 * H];
+    in.cn = st.c_new[(long)b * st.ldc_new + u];
+    in.cp = st.c_prev ? st.c_prev[(long)b * st.ldc_prev + u] : 0.f;
+    return in;
+}
+
+// no query projection (decoder / encoder LSTMs): one thread per (b, u)
+__global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(LstmBwdPointDesc d) {
+    const LstmBwdStream& st = d.st[blockIdx.y];
+    const int B = d.B, H = d.H;
+    const long i = blockIdx.x * 256l + threadIdx.x;
+    if (i >= (long)B * H) return;
+    const int b = (int)(i / H), u = (int)(i % H);
+    lstm_bwd_point(d, st, b, u, lstm_bwd_load(d, st, b, u));
+}
+
+// with the query-projection term dq . Wq (attention LSTMs): a workgroup owns PWU hidden units x PWB batch rows and
+// stages its [A x PWU] slice of Wq in LDS once.  One thread per (b, u) re-read the whole 0.5 MB Wq once per batch
+// row — 64 MB of L2->CU traffic per step, the per-CU L2 rate (~60 GB/s) made that the kernel's floor.
+constexpr int PWU = 64, PWB = 8;
+__global__ __launch_bounds__(256) void lstm_bwd_pointwise_q_kernel(LstmBwdPointDesc d) {
+    const LstmBwdStream& st = d.st[blockIdx.z];
+    const int B = d.B, H = d.H, A = st.A;
+    const int ul = threadIdx.x & (PWU - 1), bs = threadIdx.x / PWU;            // bs in 0..3, rows bs and bs + 4
+    const int u = blockIdx.x * PWU + ul, b0 = blockIdx.y * PWB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wqs = smem;                    // [A][PWU]
+    float* dqs = smem + A * PWU;          // [PWB][A]
+    // per-item operands first (cold), then the Wq slice (L2-resident)
+    PwIn in[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) in[r] = lstm_bwd_load(d, st, min(b0 + bs + 4 * r, B - 1), u);
+    if (st.dq) {
+        for (int a = bs; a < A; a += 4) wqs[a * PWU + ul] = st.wq[(long)a * H + u];
+        for (int i = threadIdx.x; i < PWB * A; i += 256) {
+            const int b = min(b0 + i / A, B - 1);
+            dqs[i] = st.dq[(long)b * st.lddq + i % A];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const float* q = dqs + (bs + 4 * r) * A;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int a = 0; a < A; a += 4) {
+                a0 += q[a] * wqs[a * PWU + ul]; a1 += q[a + 1] * wqs[(a + 1) * PWU + ul];
+                a2 += q[a + 2] * wqs[(a + 2) * PWU + ul]; a3 += q[a + 3] * wqs[(a + 3) * PWU + ul];
+            }
+            in[r].dh += (a0 + a1) + (a2 + a3);
+        }
     }
-    st.dc_state[i] = dcn * fg;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int b = b0 + bs + 4 * r;
+        if (b < B) lstm_bwd_point(d, st, b, u, in[r]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -744,8 +791,22 @@ int lstm_step_fwd(const LstmStepDesc& d, hipStream_t s) {
 
 int lstm_bwd_pointwise(const LstmBwdPointDesc& d, hipStream_t s) {
     T2_REQUIRE(d.nstreams >= 1 && d.nstreams <= kMaxLstmStreams, "lstm_bwd_pointwise: nstreams=%d", d.nstreams);
-    const long n = (long)d.B * d.H;
-    hipLaunchKernelGGL(lstm_bwd_pointwise_kernel, dim3((unsigned)((n + 255) / 256), d.nstreams), dim3(256), 0, s, d);
+    bool hasq = false;
+    int amax = 0;
+    for (int i = 0; i < d.nstreams; ++i) {
+        T2_REQUIRE(!d.st[i].dq || (d.st[i].A % 4 == 0 && d.st[i].A <= 256), "lstm_bwd_pointwise: attention dim %d unsupported", d.st[i].A);
+        hasq = hasq || d.st[i].dq;
+        if (d.st[i].dq) amax = std::max(amax, d.st[i].A);
+    }
+    if (hasq && d.H % PWU == 0) {
+        const size_t smem = (size_t)amax * (PWU + PWB) * sizeof(float);
+        T2_TRY_RC(allow_big_lds(lstm_bwd_pointwise_q_kernel, smem));
+        hipLaunchKernelGGL(lstm_bwd_pointwise_q_kernel, dim3(d.H / PWU, (d.B + PWB - 1) / PWB, d.nstreams), dim3(256), smem, s, d);
+    } else {
+        T2_REQUIRE(!hasq, "lstm_bwd_pointwise: H=%d must be a multiple of %d with a query projection", d.H, PWU);
+        const long n = (long)d.B * d.H;
+        hipLaunchKernelGGL(lstm_bwd_pointwise_kernel, dim3((unsigned)((n + 255) / 256), d.nstreams), dim3(256), 0, s, d);
+    }
     T2_LAUNCH_CHECK();
     return 0;
 }

@@ -87,6 +87,14 @@ def apply_gradient_allreduce(module):
     def launch(i):
         lo, hi = arena.ranges[i]
         seg = arena.flat[lo:hi]
+        # the model may run part of its backward on a side stream (model.BERT_Tacotron2._fronts): a bucket can hold
+        # gradients accumulated on either stream, so the launching stream first waits for the other one
+        side = getattr(module, "_t2_side", None)
+        if side is not None and seg.is_cuda:
+            cur = torch.cuda.current_stream()
+            for st in (side, torch.cuda.default_stream()):
+                if st != cur:
+                    cur.wait_stream(st)
         seg.mul_(1.0 / world)
         arena.handles.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
         arena.launched[i] = True

@@ -245,6 +245,7 @@ class BERT_Tacotron2(nn.Module):
         self.linear_converter_sub = LinearNorm(hp.encoder_embedding_dim + hp.BERT_embedding_dim, hp.encoder_embedding_dim)
         self.decoder = Decoder(hp)
         self.postnet = Postnet(hp)
+        self.overlap_encoders, self._t2_side = True, None
 
     def parse_batch(self, batch):
         """model.py:517-529: 10-tuple -> (x 9-tuple, y 3-tuple) on the GPU."""
@@ -274,12 +275,29 @@ class BERT_Tacotron2(nn.Module):
         cat = torch.cat([h, cls[:, :h.size(1)]], 2)
         return blocks.linear(cat, conv.linear_layer.weight, conv.linear_layer.bias)
 
+    def _fronts(self, text, tl, pcls, sub_ids, bl, bcls, seed):
+        """Both front ends.  They are independent until the decoder and each is a chain of small launches (three
+        conv+BN layers, a BiLSTM recurrence), so the sub-word one runs on a side stream next to the phone one;
+        autograd replays each backward on its forward stream.  `overlap_encoders = False` keeps one stream."""
+        if not (self.overlap_encoders and text.is_cuda):
+            return self._front(text, tl, pcls, False, seed), self._front(sub_ids, bl, bcls, True, seed)
+        cur = torch.cuda.current_stream()
+        if self._t2_side is None:
+            self._t2_side = torch.cuda.Stream(device=text.device)
+        side = self._t2_side
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            memory_sub = self._front(sub_ids, bl, bcls, True, seed)
+        memory = self._front(text, tl, pcls, False, seed)
+        cur.wait_stream(side)
+        memory_sub.record_stream(cur)
+        return memory, memory_sub
+
     def forward(self, inputs):
         text, tl, bl, mels, _, ol, sub_ids, pcls, bcls = inputs
         tl, bl, ol = tl.data, bl.data, ol.data
         seed = _next_seed(self)
-        memory = self._front(text, tl, pcls, False, seed)
-        memory_sub = self._front(sub_ids, bl, bcls, True, seed)
+        memory, memory_sub = self._fronts(text, tl, pcls, sub_ids, bl, bcls, seed)
         mel_btc, gate, al, alb = self.decoder(memory, memory_sub, mels, tl, bl, channels_last=True)
         post_btc = self.postnet.forward_btc(mel_btc, seed)                      # mel + postnet(mel), [B,T,n_mel]
         if self.mask_padding and ol is not None:
@@ -297,8 +315,7 @@ class BERT_Tacotron2(nn.Module):
 
     def inference(self, inputs, embeddings, phoneme_embeddings_cls, bert_embeddings_cls):
         seed = _next_seed(self)
-        memory = self._front(inputs, None, phoneme_embeddings_cls, False, seed)
-        memory_sub = self._front(embeddings, None, bert_embeddings_cls, True, seed)
+        memory, memory_sub = self._fronts(inputs, None, phoneme_embeddings_cls, embeddings, None, bert_embeddings_cls, seed)
         mel_btc, gate, al, alb, flag = self.decoder.inference(memory, memory_sub, channels_last=True)
         mel_btc = mel_btc.contiguous()
         post_btc = self.postnet.forward_btc(mel_btc, seed)
