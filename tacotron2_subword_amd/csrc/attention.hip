@@ -217,22 +217,29 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
 //   dp_j   = a_{t-1}[j] (g_j - g_{j+1}) ;  de_j = dp_j p_j (1 - p_j)
 //   u_jk   = tanh(q_k + pm_jk) ;  dpre_jk = de_j v_k (1 - u_jk^2)
 //   dq_k   = sum_j dpre_jk ; dv_k += sum_j de_j u_jk ; dpm_jk += dpre_jk
-//   carry_j <- g_j p_j + g_{j+1} (1 - p_j)                            gradient on a_{t-1}[j]
+//   carry_out_j = g_j p_j + g_{j+1} (1 - p_j)                         gradient on a_{t-1}[j]
 // ---------------------------------------------------------------------------------------------
 constexpr int NTB = 512;     // 8 waves (1024 threads spill at 128 VGPRs); MAXI (= ceil(A/64)) sizes the per-lane dq/dv accumulators
 
+// The memory positions of an item can be split over d.nsplit workgroups (blockIdx.z): each takes a contiguous range
+// [jb, je), recomputes the (cheap) total ctx gradient, needs one extra g value at je for the recurrence, and emits its
+// own partial of dq / dv (consumers add the partials).  With B*2 = 128 workgroups the kernel was bound by what one CU
+// can pull from L2/MALL (~0.36 MB per item); two workgroups per item use all 256 CUs.
 template <int MAXI>
 __global__ __launch_bounds__(NTB) void attention_step_bwd_kernel(AttnBwdDesc d) {
     const AttnBwdStream& st = d.st[blockIdx.y];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, split = blockIdx.z;
     const int Tin = st.Tin, A = d.A, E = d.E;
-    const int Tp = (Tin + 3) & ~3;
+    const int chunk = (((Tin + d.nsplit - 1) / d.nsplit) + 3) & ~3;
+    const int jb = min(split * chunk, Tin), je = min(jb + chunk, Tin), len = je - jb;
+    const int ng = je < Tin ? len + 1 : len;          // g values computed here: positions [jb, jb + ng)
+    const int Tp = chunk + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dctx = smem;              // [E]
     float* q = dctx + E;             // [A]
     float* vs = q + A;               // [A]
-    float* g = vs + A;               // [Tp + 1]  (g[Tin] = 0)
-    float* de = g + Tp + 4;          // [Tp]
+    float* g = vs + A;               // [Tp]  g[jl] = g_{jb+jl}; g[len] = g_{je} (0 past the end)
+    float* de = g + Tp;              // [Tp]
     float* ps = de + Tp;             // [Tp]
     float* red = ps + Tp;            // [NT/16][A] x 2 (dq, dv partials of the NT/16 position groups)
 
@@ -251,26 +258,34 @@ __global__ __launch_bounds__(NTB) void attention_step_bwd_kernel(AttnBwdDesc d) 
             v += acc;
         }
         dctx[c] = v;
-        st.dctx_out[(long)b * st.lddctx_out + c] = v;
+        if (split == 0) st.dctx_out[(long)b * st.lddctx_out + c] = v;
     }
     for (int a = tid; a < A; a += NTB) { q[a] = st.q[(long)b * st.ldq + a]; vs[a] = st.v[a]; }
-    for (int j = tid; j < Tin; j += NTB) ps[j] = st.p[(long)b * st.ldp + j];
-    if (tid == 0) g[Tin] = 0.f;
+    for (int jl = tid; jl < len; jl += NTB) ps[jl] = st.p[(long)b * st.ldp + jb + jl];
+    if (tid == 0) g[len] = 0.f;
     __syncthreads();
+    if (len == 0) {                                   // (only when Tin is tiny) nothing to do but the partial outputs
+        for (int a = tid; a < A; a += NTB) {
+            st.dq_out[(long)b * st.lddq_out + split * A + a] = 0.f;
+            float* dvp = st.dv_acc + ((long)split * d.B + b) * A + a;
+            if (d.first) *dvp = 0.f;
+        }
+        return;
+    }
 
     // g_j: one wave per position, lanes stride the E channels 16 B at a time; 4 positions are in
     // flight per wave so that the row loads overlap instead of serialising on L2 latency
     {
         const int wave = tid >> 6, lane = tid & 63;
         constexpr int NWV = NTB / 64, U = 4;
-        for (int j0 = wave; j0 < Tin; j0 += NWV * U) {
+        for (int j0 = wave; j0 < ng; j0 += NWV * U) {
             float sum[U] = {0.f, 0.f, 0.f, 0.f};
             for (int c = lane * 4; c < E; c += 256) {
                 const f32x4 dc = *reinterpret_cast<const f32x4*>(dctx + c);
                 f32x4 mv[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {           // clamp instead of branching: the U loads issue back to back
-                    const int j = min(j0 + u * NWV, Tin - 1);
+                    const int j = jb + min(j0 + u * NWV, ng - 1);
                     mv[u] = *reinterpret_cast<const f32x4*>(st.memory + ((long)b * Tin + j) * E + c);
                 }
 #pragma unroll
@@ -278,24 +293,28 @@ __global__ __launch_bounds__(NTB) void attention_step_bwd_kernel(AttnBwdDesc d) 
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int j = j0 + u * NWV;
+                const int jl = j0 + u * NWV;
                 const float tot = wave_sum(sum[u]);
-                if (lane == 0 && j < Tin) {
+                if (lane == 0 && jl < ng) {
+                    const int j = jb + jl;
                     float gsum = tot;
                     if (st.dalign) gsum += st.dalign[(long)b * st.lddalign + j];
                     if (!d.first) gsum += st.carry[(long)b * Tin + j];
-                    g[j] = gsum;
+                    g[jl] = gsum;
                 }
             }
         }
     }
     __syncthreads();
-    for (int j = tid; j < Tin; j += NTB) {
+    // carry is read at position je too, which the next split's workgroup updates: the new carry therefore goes to a
+    // second buffer (carry / carry_out swap roles every step)
+    for (int jl = tid; jl < len; jl += NTB) {
+        const int j = jb + jl;
         const float ap = st.a_prev ? st.a_prev[(long)b * st.lda_prev + j] : (j == 0 ? 1.f : 0.f);
-        const float p = ps[j];
-        const float gj = g[j], gn = g[j + 1];
-        de[j] = ap * (gj - gn) * p * (1.0f - p);
-        st.carry[(long)b * Tin + j] = gj * p + gn * (1.0f - p);
+        const float p = ps[jl];
+        const float gj = g[jl], gn = g[jl + 1];
+        de[jl] = ap * (gj - gn) * p * (1.0f - p);
+        st.carry_out[(long)b * Tin + j] = gj * p + gn * (1.0f - p);
     }
     __syncthreads();
 
@@ -307,10 +326,10 @@ __global__ __launch_bounds__(NTB) void attention_step_bwd_kernel(AttnBwdDesc d) 
         for (int i = 0; i < MAXI; ++i)
 #pragma unroll
             for (int c = 0; c < 4; ++c) { dq[i][c] = 0.f; dv[i][c] = 0.f; }
-        for (int j = gid; j < Tin; j += NTB / 16) {
-            const float dej = de[j];
-            const float* pmr = st.pm + ((long)b * Tin + j) * A;
-            float* dpr = st.dpm_acc + ((long)b * Tin + j) * A;
+        for (int jl = gid; jl < len; jl += NTB / 16) {
+            const float dej = de[jl];
+            const float* pmr = st.pm + ((long)b * Tin + jb + jl) * A;
+            float* dpr = st.dpm_acc + ((long)b * Tin + jb + jl) * A;
 #pragma unroll
             for (int i = 0; i < MAXI; ++i) {
                 const int a = sub * 4 + 64 * i;
@@ -343,13 +362,12 @@ __global__ __launch_bounds__(NTB) void attention_step_bwd_kernel(AttnBwdDesc d) 
         for (int a = tid; a < A; a += NTB) {
             float sq = 0.f, sv = 0.f;
             for (int k = 0; k < NTB / 16; ++k) { sq += rq[k * A + a]; sv += rv[k * A + a]; }
-            st.dq_out[(long)b * st.lddq_out + a] = sq;
-            float* dvp = st.dv_acc + (long)b * A + a;
+            st.dq_out[(long)b * st.lddq_out + split * A + a] = sq;
+            float* dvp = st.dv_acc + ((long)split * d.B + b) * A + a;
             *dvp = (d.first ? 0.f : *dvp) + sv;
         }
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Backward of one LocationSensitiveAttention step (reverse time), one workgroup per (b, stream).
@@ -677,17 +695,20 @@ int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s) {
         T2_REQUIRE(smem <= 160 * 1024, "attention_bwd (LSA): T_in=%d too long for LDS (%zu bytes > 160 KiB)", Tmax, smem);
         return d.A <= 128 ? launch_lsa_bwd<2>(d, smem, s) : launch_lsa_bwd<4>(d, smem, s);
     }
-    const int Tp = (Tmax + 3) & ~3;
-    const size_t smem = ((size_t)d.E + 2 * d.A + (Tp + 4) + 2 * Tp + 2 * (NTB / 16) * (size_t)d.A) * sizeof(float);
+    T2_REQUIRE(d.nsplit >= 1 && d.nsplit <= 4, "attention_bwd: nsplit=%d", d.nsplit);
+    for (int i = 0; i < d.nstreams; ++i) T2_REQUIRE(d.st[i].carry_out && d.st[i].carry_out != d.st[i].carry, "attention_bwd: carry_out must be a second buffer");
+    const int chunk = (((Tmax + d.nsplit - 1) / d.nsplit) + 3) & ~3;
+    const size_t smem = ((size_t)d.E + 2 * d.A + 3 * (size_t)(chunk + 4) + 2 * (NTB / 16) * (size_t)d.A) * sizeof(float);
     T2_REQUIRE(smem <= 160 * 1024, "attention_bwd: T_in too long for LDS (%zu bytes)", smem);
+    const dim3 grid(d.B, d.nstreams, d.nsplit);
     if (d.A <= 128) {
         if (smem > 64 * 1024)
             T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_step_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(attention_step_bwd_kernel<2>, dim3(d.B, d.nstreams), dim3(NTB), smem, s, d);
+        hipLaunchKernelGGL(attention_step_bwd_kernel<2>, grid, dim3(NTB), smem, s, d);
     } else {
         if (smem > 64 * 1024)
             T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_step_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(attention_step_bwd_kernel<4>, dim3(d.B, d.nstreams), dim3(NTB), smem, s, d);
+        hipLaunchKernelGGL(attention_step_bwd_kernel<4>, grid, dim3(NTB), smem, s, d);
     }
     T2_LAUNCH_CHECK();
     return 0;

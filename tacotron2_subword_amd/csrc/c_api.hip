@@ -389,6 +389,11 @@ __global__ void init_stop_kernel(int32_t* stop_index, int32_t* done, int B) {
 
 
 // ------------------------------------------------------------------------------- backward
+// SMA attention backward: two workgroups per (item, stream) when one each would leave CUs idle
+int attn_bwd_nsplit(const t2_dims& d, const Sizes& z) {
+    return (d.attention_kind == T2_ATTN_SMA && z.B * z.NS <= 128 && std::min(z.Tin, z.NS == 2 ? z.Tsub : z.Tin) >= 16) ? 2 : 1;
+}
+
 void bwd_layout_of(const t2_dims& d, const Sizes& z, t2_decoder_bwd_layout* L) {
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += align4(n); return o; };
@@ -397,10 +402,10 @@ void bwd_layout_of(const t2_dims& d, const Sizes& z, t2_decoder_bwd_layout* L) {
     L->ddout = take(BT * z.WO); L->ddin = take(BT * z.WD);
     L->dgd = take(BT * 4 * z.Hd); L->dga = take(BT * 4 * z.Ha); L->dgas = take(BT * 4 * z.Ha);
     L->dctx = take(BT * z.E); L->dctxs = take(BT * z.E);
-    L->dq = take(BT * z.A); L->dqs = take(BT * z.A);
-    L->dv = take((size_t)z.B * z.A); L->dvs = take((size_t)z.B * z.A);
+    L->dq = take(BT * 2 * z.A); L->dqs = take(BT * 2 * z.A);              // rows [2][A]: one partial per position split
+    L->dv = take((size_t)2 * z.B * z.A); L->dvs = take((size_t)2 * z.B * z.A);
     L->dpm = take((size_t)z.B * z.Tin * z.A); L->dpms = take((size_t)z.B * z.Tsub * z.A);
-    L->carry = take((size_t)z.B * z.Tin); L->carrys = take((size_t)z.B * z.Tsub);
+    L->carry = take((size_t)2 * z.B * z.Tin); L->carrys = take((size_t)2 * z.B * z.Tsub);   // ping-pong by step parity
     const bool lsa = d.attention_kind == T2_ATTN_LSA;          // LSA: cumulative-weight carry + per-item location-layer gradients
     const size_t ncv = lsa ? (size_t)z.B * d.loc_filters * 2 * d.loc_kernel : 0, nds = lsa ? (size_t)z.B * z.A * d.loc_filters : 0;
     L->carryc = take(lsa ? (size_t)z.B * z.Tin : 0); L->carrycs = take(lsa ? (size_t)z.B * z.Tsub : 0);
@@ -488,6 +493,7 @@ int att_bwd_step(const Bwd& c, int t) {
     AttnBwdDesc ab{};
     ab.nstreams = z.NS; ab.B = z.B; ab.A = z.A; ab.E = z.E; ab.first = first;
     ab.kind = c.d.attention_kind; ab.F = c.d.loc_filters; ab.Kc = c.d.loc_kernel;
+    ab.nsplit = attn_bwd_nsplit(c.d, z);
     for (int s = 0; s < z.NS; ++s) {
         AttnBwdStream& st = ab.st[s];
         const int Tin = s ? z.Tsub : z.Tin;
@@ -515,9 +521,11 @@ int att_bwd_step(const Bwd& c, int t) {
             st.dconv_acc = c.S(s ? c.BL.dlconvs : c.BL.dlconv);
             st.ddense_acc = c.S(s ? c.BL.dldenses : c.BL.dldense);
         }
-        st.carry = c.S(s ? c.BL.carrys : c.BL.carry);
+        float* cbuf = c.S(s ? c.BL.carrys : c.BL.carry);
+        if (ab.kind == T2_ATTN_SMA) { st.carry = cbuf + (size_t)((t + 1) & 1) * z.B * Tin; st.carry_out = cbuf + (size_t)(t & 1) * z.B * Tin; }
+        else st.carry = cbuf;
         st.dctx_out = c.S(s ? c.BL.dctxs : c.BL.dctx) + c.R(t) * z.E; st.lddctx_out = z.E;
-        st.dq_out = c.S(s ? c.BL.dqs : c.BL.dq) + c.R(t) * z.A; st.lddq_out = z.A;
+        st.dq_out = c.S(s ? c.BL.dqs : c.BL.dq) + c.R(t) * 2 * z.A; st.lddq_out = 2 * z.A;
         st.dv_acc = c.S(s ? c.BL.dvs : c.BL.dv);
         st.dpm_acc = c.S(s ? c.BL.dpms : c.BL.dpm);
     }
@@ -531,7 +539,7 @@ int att_bwd_step(const Bwd& c, int t) {
         const int hoff = s ? z.Ha + z.E : 0;
         st.dh1 = c.S(c.BL.ddin) + c.R(t) * z.WD + hoff; st.lddh1 = z.WD;
         st.part = c.S(c.BL.parta) + (size_t)s * ks * z.B * NC; st.nparts = ks; st.part_stride = (long)z.B * NC; st.ldpart = NC; st.part_col = z.E;
-        st.dq = c.S(s ? c.BL.dqs : c.BL.dq) + c.R(t) * z.A; st.lddq = z.A;
+        st.dq = c.S(s ? c.BL.dqs : c.BL.dq) + c.R(t) * 2 * z.A; st.lddq = 2 * z.A; st.dq_parts = ab.nsplit;
         st.wq = s ? c.w.attn_sub.wq : c.w.attn.wq; st.A = z.A;
         st.gates = c.W(s ? c.L.gas : c.L.ga) + c.R(t) * 4 * z.Ha; st.ldgates = 4 * z.Ha;
         st.c_new = c.W(s ? c.L.cnas : c.L.cna) + c.R(t) * z.Ha; st.ldc_new = z.Ha;
@@ -741,8 +749,11 @@ int t2_decoder_backward(const t2_dims* dims, const t2_decoder_weights* w, const 
         T2_TRY(relu_drop_bwd(dP1, P1, dP1, scale, (size_t)BT * z.P, c.s));
         T2_TRY(gemm(matmul_tn(c, dP1, z.P, c.W(L.x), z.M, s ? g->prenet_sub_w1 : g->prenet_w1, z.M, z.P, z.M, BT), c.s));
         // attention parameters
-        T2_TRY(gemm(matmul_tn(c, c.S(s ? BL.dqs : BL.dq), z.A, DIN + hoff, z.WD, ag.wq, z.Ha, z.A, z.Ha, BT), c.s));
-        T2_TRY(batch_sum(c.S(s ? BL.dvs : BL.dv), z.B, z.A, ag.v, c.s));
+        const int nsp = attn_bwd_nsplit(*dims, z);
+        float* DQ = c.S(s ? BL.dqs : BL.dq);
+        if (nsp == 2) T2_TRY(fold_halves(DQ, BT, z.A, c.s));               // dq row = partial 0 + partial 1
+        T2_TRY(gemm(matmul_tn(c, DQ, 2 * z.A, DIN + hoff, z.WD, ag.wq, z.Ha, z.A, z.Ha, BT), c.s));
+        T2_TRY(batch_sum(c.S(s ? BL.dvs : BL.dv), nsp * z.B, z.A, ag.v, c.s));
         if (dims->attention_kind == T2_ATTN_LSA) {
             T2_REQUIRE(ag.loc_conv && ag.loc_dense, "t2_decoder_backward: LSA needs loc_conv / loc_dense gradient buffers");
             T2_TRY(batch_sum(c.S(s ? BL.dlconvs : BL.dlconv), z.B, dims->loc_filters * 2 * dims->loc_kernel, ag.loc_conv, c.s));

@@ -112,6 +112,13 @@ __global__ void colsum_stage2_kernel(const float* __restrict__ scratch, int N, i
     out[n] = acc;
     if (out2) out2[n] = acc;
 }
+__global__ void fold_halves_kernel(float* __restrict__ X, size_t rows, int A) {
+    const size_t n = rows * A;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float* r = X + (i / A) * 2 * A + (i % A);
+        r[0] += r[A];
+    }
+}
 __global__ void batch_sum_kernel(const float* __restrict__ X, int B, int n, float* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -138,6 +145,11 @@ int colsum(const float* X, long ld, int M, int N, float* out, float* out2, float
     hipLaunchKernelGGL(colsum_stage1_kernel, dim3((N + 63) / 64, slabs), dim3(256), 0, s, X, ld, M, N, slabs, scratch);
     T2_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, s, scratch, N, slabs, out, out2);
+    T2_LAUNCH_CHECK();
+    return 0;
+}
+int fold_halves(float* X, size_t rows, int A, hipStream_t s) {
+    hipLaunchKernelGGL(fold_halves_kernel, dim3(grid_for(rows * A)), dim3(256), 0, s, X, rows, A);
     T2_LAUNCH_CHECK();
     return 0;
 }

@@ -69,6 +69,7 @@ struct LstmBwdStream {
     const float* part; int nparts; long part_stride; long ldpart; int part_col;   // recurrent partials from
                                            // lstm_bwd_gemm of step t+1: sum_z part[z*part_stride + b*ldpart + part_col + u]
     const float* dq; long lddq; const float* wq; int A;   // + dq[b,:] . wq[:,u]  (query projection, nullable)
+    int dq_parts;                          // dq row = dq_parts partials of A columns each, summed here (0 -> 1)
     const float* gates; long ldgates;      // saved activated gates of step t
     const float* c_new; long ldc_new;      // saved cell before dropout
     const float* c_prev; long ldc_prev;    // cell carried INTO step t (after dropout), null -> 0
@@ -132,10 +133,11 @@ struct AttnBwdStream {
     const float* p; long ldp;              // saved selection probability of step t
     const float* a_prev; long lda_prev;    // alignment of step t-1 (null at t=0 -> one-hot)
     const float* v;
-    float* carry;                          // [B,Tin] gradient flowing into a_{t} from step t+1 (in/out)
+    float* carry;                          // [B,Tin] gradient flowing into a_{t} from step t+1 (LSA: updated in place)
+    float* carry_out;                      // SMA: [B,Tin] gradient for step t-1 (a second buffer; the two swap every step)
     float* dctx_out; long lddctx_out;      // [B,E] total ctx gradient, saved for the d(memory) GEMM
-    float* dq_out; long lddq_out;          // [B,A]
-    float* dv_acc;                         // [B,A] accumulated over steps
+    float* dq_out; long lddq_out;          // [B, nsplit*A]: one partial per position split (columns split*A ...)
+    float* dv_acc;                         // [nsplit][B][A] accumulated over steps
     float* dpm_acc;                        // [B,Tin,A] accumulated over steps
     int Tin;
     // LSA only
@@ -145,7 +147,7 @@ struct AttnBwdStream {
     float* carry_cum;                      // [B,Tin] gradient on the cumulative weights (in/out); `carry` holds the w_{t-1} part
     float* dconv_acc; float* ddense_acc;   // [B,F*2*Kc], [B,A*F] per-item weight gradients accumulated over steps
 };
-struct AttnBwdDesc { AttnBwdStream st[2]; int nstreams; int B, A, E; int first; int kind, F, Kc; };
+struct AttnBwdDesc { AttnBwdStream st[2]; int nstreams; int B, A, E; int first; int kind, F, Kc; int nsplit; };   // nsplit: SMA only
 int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s);
 
 // ------------------------------------------------------------------ decode-step tail (infer.hip)
@@ -209,6 +211,8 @@ int permute_rows(const float* in, float* out, int R1, int R2, int W, hipStream_t
 int relu_drop_bwd(const float* dy, const float* y, float* dz, float scale, size_t n, hipStream_t s);
 // out[n] = sum_m X[m*ld + n]  (bias gradients; two fixed-order stages, scratch >= 64*N floats); out2 optional copy
 int colsum(const float* X, long ld, int M, int N, float* out, float* out2, float* scratch, hipStream_t s);
+// X[r, 0:A] += X[r, A:2A]   (rows of 2A floats)
+int fold_halves(float* X, size_t rows, int A, hipStream_t s);
 // out[i] = sum_b X[b*n + i]
 int batch_sum(const float* X, int B, int n, float* out, hipStream_t s);
 

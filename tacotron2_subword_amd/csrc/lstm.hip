@@ -524,9 +524,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_q_kernel(LstmBwdPointD
     for (int r = 0; r < 2; ++r) in[r] = lstm_bwd_load(d, st, min(b0 + bs + 4 * r, B - 1), u);
     if (st.dq) {
         for (int a = bs; a < A; a += 4) wqs[a * PWU + ul] = st.wq[(long)a * H + u];
+        const int parts = st.dq_parts > 0 ? st.dq_parts : 1;
         for (int i = threadIdx.x; i < PWB * A; i += 256) {
-            const int b = min(b0 + i / A, B - 1);
-            dqs[i] = st.dq[(long)b * st.lddq + i % A];
+            const float* row = st.dq + (long)min(b0 + i / A, B - 1) * st.lddq + i % A;
+            float v = row[0];
+            for (int p = 1; p < parts; ++p) v += row[p * A];
+            dqs[i] = v;
         }
         __syncthreads();
 #pragma unroll
