@@ -274,21 +274,26 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
         traffic = None                      # HBM-side bytes per launch from the committed rocprofv3 PMC passes
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-        tkey = {"att_lstm_fwd": "lstm_step_fwd_grid131072", "dec_lstm_fwd": "lstm_step_fwd_grid65536",
-                "attention_fwd": "attention_step_fwd_grid131072", "attention_bwd": "attention_step_bwd_grid65536",
-                "att_lstm_bwd_gemm": "lstm_bwd_gemm_grid393216", "dec_lstm_bwd_gemm": "lstm_bwd_gemm_grid131072"}.get(dom)
+        tkey = {"att_lstm_fwd": "lstm_step_fwd_bf16_grid131072", "dec_lstm_fwd": "lstm_step_fwd_bf16_grid65536",
+                "attention_fwd": "attention_step_fwd_grid131072", "attention_bwd": "attention_step_bwd_grid131072",
+                "att_lstm_bwd_gemm": "lstm_bwd_gemm_bf16_grid393216", "dec_lstm_bwd_gemm": "lstm_bwd_gemm_bf16_grid131072",
+                "att_lstm_bwd_pointwise": "lstm_bwd_pointwise_q_grid65536", "dec_lstm_bwd_pointwise": "lstm_bwd_pointwise_grid65536"}.get(dom)
+        if not bf or a.attention != "sma":
+            tkey = None                     # the committed PMC passes were taken in the default mode (bf16 operands, SMA)
         if os.path.exists(tpath) and tkey and (B, Tin, Tsub) == (64, 100, 60):
             traffic = json.load(open(tpath)).get(tkey, {}).get("hbm_bytes_per_launch")
         # fp32 operands: the recurrent step GEMMs sit just above the fp32-MFMA ridge (AI ~ 26 FLOP/B vs 20) -> MFMA bound;
         # bf16 operands: 16x the matrix rate -> every per-step kernel is bound by operand delivery (HBM / L2)
         if dom in fl and not bf:
             roof = dict(kernel=dom, bound="mfma", achieved=kernels[dom]["tflops"], peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(kernels[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic if not bf else None,
+                        frac=round(kernels[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
                         note="fp32 MFMA (v_mfma_f32_32x32x2_f32) peak; algorithmic FLOPs per launch / avg HIP-event duration")
         else:
             roof = dict(kernel=dom, bound="hbm", achieved=kernels[dom]["gbs"], peak=PEAK_HBM_GBS, unit="GB/s",
-                        frac=round(kernels[dom]["gbs"] / PEAK_HBM_GBS, 4), traffic=traffic if not bf or "attention" in dom else None,
-                        note="algorithmic bytes per launch (DESIGN.md section 3) / avg HIP-event duration")
+                        frac=round(kernels[dom]["gbs"] / PEAK_HBM_GBS, 4), traffic=traffic,
+                        note="algorithmic bytes per launch (DESIGN.md section 3) / avg HIP-event duration; the events bracket the "
+                             "launch, so ~3 us of dispatch gap is included (rocprofv3 kernel durations in profiles/ are that "
+                             "much shorter); traffic = HBM-side bytes per launch from the PMC passes in profiles/")
     if world > 1:
         torch.distributed.barrier()
     if rank != 0:

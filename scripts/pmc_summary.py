@@ -1,0 +1,45 @@
+"""Summarise two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) into profiles/rNN_pmc_hbm_traffic.json.
+
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o p -- python3 scripts/time_decoder.py --T 40 --iters 1 --prof 0 --overlap 0
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o p -- python3 scripts/time_decoder.py --T 40 --iters 1 --prof 0 --overlap 0
+  python scripts/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_hbm_traffic.json
+
+Per kernel (short name + grid size): median per-launch FETCH_SIZE / WRITE_SIZE in KB and
+hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 — gfx950 reports half the bytes of wide coalesced reads
+(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-byte-per-lane stores."""
+import csv, glob, json, os, re, statistics, sys
+
+
+def load(d, counter):
+    out = {}
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != counter:
+                continue
+            name = r["Kernel_Name"]
+            m = re.search(r"(\w+)_kernel", name)
+            short = m.group(1) if m else name[:40]
+            if "bf16" in name and "bf16" not in short:
+                short += "_bf16"
+            key = f"{short}_grid{r['Grid_Size']}"
+            out.setdefault(key, []).append(float(r["Counter_Value"]))
+    return out
+
+
+def main():
+    fd, wd, dst = sys.argv[1:4]
+    F, W = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
+    res = {}
+    for k in sorted(set(F) | set(W)):
+        if not any(t in k for t in ("lstm", "attention", "step", "proj", "prenet")):
+            continue
+        f = statistics.median(F.get(k, [0.0])); w = statistics.median(W.get(k, [0.0]))
+        res[k] = {"launches": len(F.get(k, [])), "FETCH_SIZE_KB_median": f, "WRITE_SIZE_KB_median": w,
+                  "hbm_bytes_per_launch": (2 * f + w) * 1024}
+    json.dump(res, open(dst, "w"), indent=1)
+    for k, v in res.items():
+        print(f"{k:50s} n={v['launches']:4d} fetch {v['FETCH_SIZE_KB_median']:10.1f} KB  write {v['WRITE_SIZE_KB_median']:9.1f} KB  hbm {v['hbm_bytes_per_launch'] / 1e6:8.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
