@@ -76,33 +76,67 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
     for (int j = tid; j < Tin; j += NT)
         ap[j] = st.a_prev ? st.a_prev[(long)b * st.lda_prev + j] : ((d.kind == 0 && j == 0) ? 1.f : 0.f);
 
-    float* loc = nullptr; float* dense = nullptr;
+    float* loc = nullptr; float* dense = nullptr; float* paS = nullptr;
+    const int F1 = F + 1, PA = A + 8;            // PA % 16 == 8: the two row-halves of an MFMA tile store to disjoint banks
     if (d.kind == 1) {
         float* convw = lsa;
         dense = convw + F * 2 * Kc;
-        loc = dense + A * (F + 1);
-        float* wpad = loc + Tin * (F + 1);
-        const int pad = (Kc - 1) / 2, Tw = Tin + Kc - 1;
+        loc = dense + A * F1;
+        float* wpad = loc + ((Tin * F1 + 3) & ~3);
+        const int pad = (Kc - 1) / 2, Tw = Tin + Kc - 1, TwP = (Tw + 4 + 3) & ~3;
+        if (d.lsa_pa) paS = wpad + 2 * TwP;
         for (int i = tid; i < F * 2 * Kc; i += NT) convw[i] = st.loc_conv[i];
-        for (int i = tid; i < A * F; i += NT) dense[(i / F) * (F + 1) + (i % F)] = st.loc_dense[i];
-        for (int i = tid; i < 2 * Tw; i += NT) {
-            const int c = i / Tw, j = i % Tw - pad;
+        for (int i = tid; i < A * F1; i += NT) dense[i] = (i % F1) < F ? st.loc_dense[(i / F1) * F + (i % F1)] : 0.f;
+        for (int i = tid; i < 2 * TwP; i += NT) {
+            const int c = i / TwP, j = i % TwP - pad;
             float v = 0.f;
             if (j >= 0 && j < Tin) v = c == 0 ? (st.a_prev ? st.a_prev[(long)b * st.lda_prev + j] : 0.f)
                                               : (st.wcum_prev ? st.wcum_prev[(long)b * st.ldwcum_prev + j] : 0.f);
             wpad[i] = v;
         }
         __syncthreads();
-        // location conv: loc[j][f] = sum_c sum_k convw[f][c][k] * wcat[c][j + k - pad]
-        for (int i = tid; i < Tin * F; i += NT) {
-            const int j = i / F, f = i % F;
-            float sum = 0.f;
+        // location conv: loc[j][f] = sum_c sum_k convw[f][c][k] * wcat[c][j + k - pad]; one thread per (f, 4 positions):
+        // the sliding window lives in registers, 2 LDS reads per 4 MACs
+        const int nj4 = (Tin + 3) / 4;
+        for (int i = tid; i < nj4 * F; i += NT) {
+            const int f = i % F, j0 = (i / F) * 4;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
             for (int c = 0; c < 2; ++c) {
                 const float* w = convw + (f * 2 + c) * Kc;
-                const float* x = wpad + c * Tw + j;
-                for (int k = 0; k < Kc; ++k) sum += w[k] * x[k];
+                const float* x = wpad + c * TwP + j0;
+                float x0 = x[0], x1 = x[1], x2 = x[2];
+                for (int k = 0; k < Kc; ++k) {
+                    const float x3 = x[k + 3], wk = w[k];
+                    a0 += wk * x0; a1 += wk * x1; a2 += wk * x2; a3 += wk * x3;
+                    x0 = x1; x1 = x2; x2 = x3;
+                }
             }
-            loc[j * (F + 1) + f] = sum;
+            loc[j0 * F1 + f] = a0;
+            if (j0 + 1 < Tin) loc[(j0 + 1) * F1 + f] = a1;
+            if (j0 + 2 < Tin) loc[(j0 + 2) * F1 + f] = a2;
+            if (j0 + 3 < Tin) loc[(j0 + 3) * F1 + f] = a3;
+        }
+        for (int j = tid; j < Tin; j += NT) loc[j * F1 + F] = 0.f;      // pad column (K rounded up to even for the MFMA)
+        if (paS) {
+            // location features through the dense layer on the matrix cores: pa[j][a] = sum_f loc[j][f] * Wd[a][f]
+            // (exact fp32 fma chains, v_mfma_f32_32x32x2_f32), one 32x32 tile per wave
+            __syncthreads();
+            const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+            const int njt = (Tin + 31) / 32, nat = A / 32, Ke = (F + 1) & ~1;
+            for (int tile = wave; tile < njt * nat; tile += NT / 64) {
+                const int jt = tile / nat, at = tile % nat;
+                const float* lr = loc + min(jt * 32 + r, Tin - 1) * F1 + h;
+                const float* dr = dense + (at * 32 + r) * F1 + h;
+                f32x16 acc;
+#pragma unroll
+                for (int e2 = 0; e2 < 16; ++e2) acc[e2] = 0.f;
+                for (int kk = 0; kk < Ke; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lr[kk], dr[kk], acc, 0, 0, 0);
+#pragma unroll
+                for (int e2 = 0; e2 < 16; ++e2) {
+                    const int row = jt * 32 + (e2 & 3) + 8 * (e2 >> 2) + 4 * h;
+                    if (row < Tin) paS[row * PA + at * 32 + r] = acc[e2];
+                }
+            }
         }
     }
     __syncthreads();
@@ -120,11 +154,14 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
                     for (int c = 0; c < 4; ++c) {
                         float u = q[a + c] + pv[c];
                         if (d.kind == 1) {
-                            float pa = 0.f;
-                            const float* dr = dense + (a + c) * (F + 1);
-                            const float* lr = loc + j * (F + 1);
-                            for (int f = 0; f < F; ++f) pa += dr[f] * lr[f];
-                            u += pa;
+                            if (paS) u += paS[j * PA + a + c];
+                            else {
+                                float pa = 0.f;
+                                const float* dr = dense + (a + c) * F1;
+                                const float* lr = loc + j * F1;
+                                for (int f = 0; f < F; ++f) pa += dr[f] * lr[f];
+                                u += pa;
+                            }
                         }
                         sum += vs[a + c] * tanhf(u);
                     }
@@ -641,26 +678,349 @@ __global__ __launch_bounds__(NTB) void attention_lsa_step_bwd_kernel(AttnBwdDesc
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// LSA backward, matrix-core variant (used when the [T_in][A] tile fits in LDS; same math and outputs as
+// attention_lsa_step_bwd_kernel above).  The four contractions of the location layer run as fp32 MFMAs
+// (v_mfma_f32_32x32x2_f32, exact fma chains) on one [T_in][A] LDS tile that first holds
+// pa = loc . Wd^T and is then overwritten in place by dpre:
+//     pa     [Tin x A]  = loc  [Tin x F] . Wd^T           dloc [Tin x F] = dpre [Tin x A] . Wd
+//     dWd    [A x F]   += dpre^T . loc                     dWc  [F x 2Kc] += dloc^T . toeplitz(wcat)
+// 1024 threads: 16 waves; the scalar version spent ~110 us per step on LDS operand reads.
+// ---------------------------------------------------------------------------------------------
+constexpr int NTL = 1024;
+constexpr int NQ2 = 8;            // f-groups of the dwcat contraction
+
+struct LsaMfmaSmem { int dctx, q, vs, g, w, de, wpad, convw, dense, loc, dlocP, PD, red, red2, tmp, total; int TwP, TinE, PA, F1; };
+__host__ __device__ inline LsaMfmaSmem lsa_mfma_smem(int Tin, int A, int E, int F, int Kc) {
+    LsaMfmaSmem m; int o = 0;
+    const int Tp = (Tin + 3) & ~3;
+    m.TwP = (Tin + Kc - 1 + 4 + 3) & ~3; m.TinE = (Tin + 1) & ~1; m.PA = A + 8; m.F1 = F + 1;
+    auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+    m.dctx = take(E); m.q = take(A); m.vs = take(A); m.g = take(Tp); m.w = take(Tp); m.de = take(Tp);
+    m.wpad = take(2 * m.TwP); m.convw = take(F * 2 * Kc); m.dense = take(A * m.F1);
+    m.loc = take(m.TinE * m.F1); m.dlocP = take((Tin + Kc - 1 + 4) * m.F1); m.PD = take(m.TinE * m.PA);
+    const int nred = (NTL / 16) * A, ntmp = NQ2 * 2 * Tp;            // tmp is written after red has been consumed
+    m.red = take(nred > ntmp ? nred : ntmp); m.tmp = m.red; m.red2 = take(NTL / 64 + 4);
+    m.total = o;
+    return m;
+}
+
+__device__ __forceinline__ float block_sum_l(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < NTL / 64; ++i) r += red[i];
+    return r;
+}
+
+template <int MAXI>
+__global__ __launch_bounds__(NTL) void attention_lsa_step_bwd_mfma_kernel(AttnBwdDesc d) {
+    const AttnBwdStream& st = d.st[blockIdx.y];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int Tin = st.Tin, A = d.A, E = d.E, F = d.F, Kc = d.Kc;
+    const int pad = (Kc - 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const LsaMfmaSmem m = lsa_mfma_smem(Tin, A, E, F, Kc);
+    const int TwP = m.TwP, TinE = m.TinE, PA = m.PA, F1 = m.F1;
+    float* dctx = smem + m.dctx; float* q = smem + m.q; float* vs = smem + m.vs;
+    float* g = smem + m.g; float* wS = smem + m.w; float* de = smem + m.de;
+    float* wpad = smem + m.wpad; float* convw = smem + m.convw; float* dense = smem + m.dense;
+    float* loc = smem + m.loc; float* dlocP = smem + m.dlocP; float* PD = smem + m.PD;
+    float* red = smem + m.red; float* red2 = smem + m.red2; float* tmp = smem + m.tmp;
+
+    // ---- stage
+    for (int c = tid; c < E; c += NTL) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) if (st.dctx[i]) v += st.dctx[i][(long)b * st.lddctx[i] + c];
+        if (st.part && !d.first) {
+            const float* p = st.part + (long)b * st.ldpart + st.part_col + c;
+            float pv[8];
+#pragma unroll
+            for (int z = 0; z < 8; ++z) pv[z] = z < st.nparts ? p[(long)z * st.part_stride] : 0.f;
+            float acc = 0.f;
+#pragma unroll
+            for (int z = 0; z < 8; ++z) acc += pv[z];
+            v += acc;
+        }
+        dctx[c] = v;
+        st.dctx_out[(long)b * st.lddctx_out + c] = v;
+    }
+    for (int a = tid; a < A; a += NTL) { q[a] = st.q[(long)b * st.ldq + a]; vs[a] = st.v[a]; }
+    for (int j = tid; j < Tin; j += NTL) wS[j] = st.w[(long)b * st.ldw + j];
+    for (int i = tid; i < F * 2 * Kc; i += NTL) convw[i] = st.loc_conv[i];
+    for (int i = tid; i < A * F1; i += NTL) dense[i] = (i % F1) < F ? st.loc_dense[(i / F1) * F + (i % F1)] : 0.f;
+    for (int i = tid; i < 2 * TwP; i += NTL) {
+        const int c = i / TwP, j = i % TwP - pad;
+        float v = 0.f;
+        if (j >= 0 && j < Tin) v = c == 0 ? (st.a_prev ? st.a_prev[(long)b * st.lda_prev + j] : 0.f)
+                                          : (st.wcum_prev ? st.wcum_prev[(long)b * st.ldwcum_prev + j] : 0.f);
+        wpad[i] = v;
+    }
+    for (int i = tid; i < (Tin + Kc - 1 + 4) * F1; i += NTL) dlocP[i] = 0.f;     // rows [pad, pad+Tin) are overwritten below
+    for (int i = tid; i < (TinE - Tin) * PA; i += NTL) PD[Tin * PA + i] = 0.f;  // K of the dWd product is rounded up to even
+    for (int i = tid; i < (TinE - Tin) * F1; i += NTL) loc[Tin * F1 + i] = 0.f;
+    __syncthreads();
+
+    // ---- g_j = dctx . memory_j (+ external and carried gradients): one wave per position, 4 in flight
+    {
+        constexpr int NWV = NTL / 64, U = 4;
+        for (int j0 = wave; j0 < Tin; j0 += NWV * U) {
+            float sum[U] = {0.f, 0.f, 0.f, 0.f};
+            for (int c = lane * 4; c < E; c += 256) {
+                const f32x4 dc = *reinterpret_cast<const f32x4*>(dctx + c);
+                f32x4 mv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int j = min(j0 + u * NWV, Tin - 1);
+                    mv[u] = *reinterpret_cast<const f32x4*>(st.memory + ((long)b * Tin + j) * E + c);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) sum[u] += mv[u][0] * dc[0] + mv[u][1] * dc[1] + mv[u][2] * dc[2] + mv[u][3] * dc[3];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u * NWV;
+                const float tot = wave_sum(sum[u]);
+                if (lane == 0 && j < Tin) {
+                    float gsum = tot;
+                    if (st.dalign) gsum += st.dalign[(long)b * st.lddalign + j];
+                    if (!d.first) gsum += st.carry[(long)b * Tin + j] + st.carry_cum[(long)b * Tin + j];
+                    g[j] = gsum;
+                }
+            }
+        }
+    }
+    // ---- location conv recomputed: one thread per (f, 4 positions), sliding window in registers
+    {
+        const int nj4 = (Tin + 3) / 4;
+        for (int i = tid; i < nj4 * F; i += NTL) {
+            const int f = i % F, j0 = (i / F) * 4;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int c = 0; c < 2; ++c) {
+                const float* w = convw + (f * 2 + c) * Kc;
+                const float* x = wpad + c * TwP + j0;
+                float x0 = x[0], x1 = x[1], x2 = x[2];
+                for (int k = 0; k < Kc; ++k) {
+                    const float x3 = x[k + 3], wk = w[k];
+                    a0 += wk * x0; a1 += wk * x1; a2 += wk * x2; a3 += wk * x3;
+                    x0 = x1; x1 = x2; x2 = x3;
+                }
+            }
+            loc[j0 * F1 + f] = a0;
+            if (j0 + 1 < Tin) loc[(j0 + 1) * F1 + f] = a1;
+            if (j0 + 2 < Tin) loc[(j0 + 2) * F1 + f] = a2;
+            if (j0 + 3 < Tin) loc[(j0 + 3) * F1 + f] = a3;
+        }
+        for (int j = tid; j < Tin; j += NTL) loc[j * F1 + F] = 0.f;
+    }
+    __syncthreads();
+    const int njt = (Tin + 31) / 32, nat = A / 32;
+    // ---- pa = loc . Wd^T  -> PD
+    {
+        const int Ke = (F + 1) & ~1;
+        for (int tile = wave; tile < njt * nat; tile += NTL / 64) {
+            const int jt = tile / nat, at = tile % nat;
+            const float* lr = loc + min(jt * 32 + r, Tin - 1) * F1 + h;
+            const float* dr = dense + (at * 32 + r) * F1 + h;
+            f32x16 acc;
+#pragma unroll
+            for (int e2 = 0; e2 < 16; ++e2) acc[e2] = 0.f;
+            for (int kk = 0; kk < Ke; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lr[kk], dr[kk], acc, 0, 0, 0);
+#pragma unroll
+            for (int e2 = 0; e2 < 16; ++e2) {
+                const int row = jt * 32 + (e2 & 3) + 8 * (e2 >> 2) + 4 * h;
+                if (row < Tin) PD[row * PA + at * 32 + r] = acc[e2];
+            }
+        }
+    }
+    // ---- softmax backward
+    {
+        float part = 0.f;
+        for (int j = tid; j < Tin; j += NTL) part += wS[j] * g[j];
+        const float sdot = block_sum_l(part, red2);          // (its barriers also publish PD)
+        for (int j = tid; j < Tin; j += NTL) de[j] = wS[j] * (g[j] - sdot);
+    }
+    __syncthreads();
+
+    // ---- energies backward: 16 lanes per position; dpre overwrites pa in place
+    {
+        const int gid = tid >> 4, sub = tid & 15;
+        float dv[MAXI][4];
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dv[i][c] = 0.f;
+        for (int j = gid; j < Tin; j += NTL / 16) {
+            const float dej = de[j];
+            const float* pmr = st.pm + ((long)b * Tin + j) * A;
+            float* dpr = st.dpm_acc + ((long)b * Tin + j) * A;
+#pragma unroll
+            for (int i = 0; i < MAXI; ++i) {
+                const int a = sub * 4 + 64 * i;
+                if (a < A) {
+                    const f32x4 pv = *reinterpret_cast<const f32x4*>(pmr + a);
+                    f32x4 acc = d.first ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(dpr + a);
+                    const f32x4 pa = *reinterpret_cast<const f32x4*>(PD + j * PA + a);
+                    f32x4 dp;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float u = tanhf(q[a + c] + pa[c] + pv[c]);
+                        const float dpre = dej * vs[a + c] * (1.0f - u * u);
+                        dv[i][c] += dej * u;
+                        acc[c] += dpre;
+                        dp[c] = dpre;
+                    }
+                    *reinterpret_cast<f32x4*>(dpr + a) = acc;
+                    *reinterpret_cast<f32x4*>(PD + j * PA + a) = dp;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int a = sub * 4 + 64 * i;
+            if (a < A) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) red[gid * A + a + c] = dv[i][c];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- four independent consumers of the dpre tile, spread over the waves:
+    //   waves [0, njt):            dloc[j][f] = sum_a dpre[j][a] Wd[a][f]                (MFMA, K = A)
+    //   waves [njt, njt + nat):    dWd[a][f] += sum_j dpre[j][a] loc[j][f]               (MFMA, K = Tin)
+    //   remaining waves:           dq[a] = sum_j dpre[j][a] ; dv[a] += sum of the group partials
+    if (wave < njt) {
+        const int jt = wave;
+        const float* ar = PD + min(jt * 32 + r, TinE - 1) * PA + h;       // A[m = j][k = a]
+        const float* br = dense + h * F1 + min(r, F);                      // B[k = a][n = f]   (column F is the zero pad)
+        f32x16 acc;
+#pragma unroll
+        for (int e2 = 0; e2 < 16; ++e2) acc[e2] = 0.f;
+        for (int kk = 0; kk < A; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[kk], br[kk * F1], acc, 0, 0, 0);
+        if (r < F) {
+#pragma unroll
+            for (int e2 = 0; e2 < 16; ++e2) {
+                const int row = jt * 32 + (e2 & 3) + 8 * (e2 >> 2) + 4 * h;
+                if (row < Tin) dlocP[(row + pad) * F1 + r] = acc[e2];
+            }
+        }
+    } else if (wave < njt + nat) {
+        const int at = wave - njt;
+        const float* ar = PD + h * PA + at * 32 + r;                       // A[m = a][k = j]
+        const float* br = loc + h * F1 + min(r, F);                        // B[k = j][n = f]
+        f32x16 acc;
+#pragma unroll
+        for (int e2 = 0; e2 < 16; ++e2) acc[e2] = 0.f;
+        for (int kk = 0; kk < TinE; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[kk * PA], br[kk * F1], acc, 0, 0, 0);
+        if (r < F) {
+#pragma unroll
+            for (int e2 = 0; e2 < 16; ++e2) {
+                const int a = at * 32 + (e2 & 3) + 8 * (e2 >> 2) + 4 * h;
+                float* p = st.ddense_acc + (long)b * A * F + a * F + r;
+                *p = (d.first ? 0.f : *p) + acc[e2];
+            }
+        }
+    } else {
+        const int t0 = tid - (njt + nat) * 64, nth = NTL - (njt + nat) * 64;
+        for (int a = t0; a < A; a += nth) {
+            float sq = 0.f, sv = 0.f;
+            for (int j = 0; j < Tin; ++j) sq += PD[j * PA + a];
+            for (int k = 0; k < NTL / 16; ++k) sv += red[k * A + a];
+            st.dq_out[(long)b * st.lddq_out + a] = sq;
+            float* dvp = st.dv_acc + (long)b * A + a;
+            *dvp = (d.first ? 0.f : *dvp) + sv;
+        }
+    }
+    __syncthreads();
+    // ---- dWc[f][(c,k)] += sum_j dloc[j][f] wcat[c][j+k-pad]   (MFMA, K = Tin; waves 0..1)  |  dwcat on the other waves
+    const int ncol = 2 * Kc, nct = (ncol + 31) / 32;
+    if (wave < nct) {
+        const int n = min(wave * 32 + r, ncol - 1), c = n / Kc, k = n % Kc;
+        const float* ar = dlocP + (pad + h) * F1 + min(r, F);              // A[m = f][k = j]   (row F... column F is never written: 0)
+        const float* br = wpad + c * TwP + k + h;                          // B[k = j][n = (c,k)] = wcat[c][j + k - pad]
+        f32x16 acc;
+#pragma unroll
+        for (int e2 = 0; e2 < 16; ++e2) acc[e2] = 0.f;
+        for (int kk = 0; kk < TinE; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[kk * F1], br[kk], acc, 0, 0, 0);
+        if (wave * 32 + r < ncol) {
+#pragma unroll
+            for (int e2 = 0; e2 < 16; ++e2) {
+                const int f = (e2 & 3) + 8 * (e2 >> 2) + 4 * h;
+                if (f < F) {
+                    float* p = st.dconv_acc + (long)b * F * ncol + f * ncol + n;
+                    *p = (d.first ? 0.f : *p) + acc[e2];
+                }
+            }
+        }
+    } else if (st.a_prev) {
+        // dwcat[c][i] = sum_{f,k} Wc[f][c][k] dloc[i-k+pad][f]: work item (fq, c, 4 positions), window slides downwards
+        const int t0 = tid - nct * 64, nth = NTL - nct * 64, ni4 = (Tin + 3) / 4, Tp = (Tin + 3) & ~3;
+        for (int it = t0; it < NQ2 * 2 * ni4; it += nth) {
+            const int fq = it / (2 * ni4), c = (it / ni4) % 2, i0 = (it % ni4) * 4;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (int f = fq; f < F; f += NQ2) {
+                const float* w = convw + (f * 2 + c) * Kc;
+                const float* dl = dlocP + (i0 + 2 * pad) * F1 + f;         // row i0 - k + 2*pad at k = 0
+                float d3 = dl[3 * F1], d2 = dl[2 * F1], d1 = dl[F1];       // rows i0+3, i0+2, i0+1 (zero rows past the end)
+                for (int k = 0; k < Kc; ++k) {
+                    const float d0 = dl[-k * F1], wk = w[k];
+                    s0 += wk * d0; s1 += wk * d1; s2 += wk * d2; s3 += wk * d3;
+                    d3 = d2; d2 = d1; d1 = d0;
+                }
+            }
+            float* tp = tmp + (fq * 2 + c) * Tp + i0;
+            tp[0] = s0; tp[1] = s1; tp[2] = s2; tp[3] = s3;
+        }
+    }
+    __syncthreads();
+    if (st.a_prev) {
+        const int Tp = (Tin + 3) & ~3;
+        for (int it = tid; it < 2 * Tin; it += NTL) {
+            const int c = it / Tin, i = it % Tin;
+            float sum = 0.f;
+#pragma unroll
+            for (int fq = 0; fq < NQ2; ++fq) sum += tmp[(fq * 2 + c) * Tp + i];
+            if (c == 0) st.carry[(long)b * Tin + i] = sum;
+            else {
+                float* p = st.carry_cum + (long)b * Tin + i;
+                *p = (d.first ? 0.f : *p) + sum;
+            }
+        }
+    }
+}
+
 }  // namespace
 
-size_t attention_fwd_smem(const AttnStepDesc& d) {
+size_t attention_fwd_smem(const AttnStepDesc& d, bool with_pa) {
     int Tmax = 0;
     for (int i = 0; i < d.nstreams; ++i) Tmax = d.st[i].Tin > Tmax ? d.st[i].Tin : Tmax;
     const int Tp = (Tmax + 3) & ~3;
     const int nh = NT / (d.E / 4);
     size_t n = 2 * d.A + 3 * Tp + 4 * NT + (size_t)nh * d.E;
-    if (d.kind == 1) n += (size_t)d.F * 2 * d.Kc + (size_t)d.A * (d.F + 1) + (size_t)Tmax * (d.F + 1) + 2 * (size_t)(Tmax + d.Kc - 1);
+    if (d.kind == 1) {
+        const int TwP = (Tmax + d.Kc - 1 + 4 + 3) & ~3;
+        n += (size_t)d.F * 2 * d.Kc + (size_t)d.A * (d.F + 1) + (((size_t)Tmax * (d.F + 1) + 3) & ~(size_t)3) + 2 * (size_t)TwP;
+        if (with_pa) n += (size_t)Tmax * (d.A + 8);
+    }
     return n * sizeof(float);
 }
 
-int attention_step_fwd(const AttnStepDesc& d, hipStream_t s) {
+int attention_step_fwd(const AttnStepDesc& din, hipStream_t s) {
+    AttnStepDesc d = din;
     T2_REQUIRE(d.nstreams >= 1 && d.nstreams <= 2, "attention_step: nstreams=%d", d.nstreams);
     T2_REQUIRE(d.A % 4 == 0 && d.A <= 256 && NT % (d.A / 4) == 0, "attention_step: attention_dim %d must be a multiple of 4 dividing %d, <= 256", d.A, 4 * NT);
     T2_REQUIRE(d.E % 4 == 0 && d.E / 4 <= NT && NT % (d.E / 4) == 0, "attention_step: encoder dim %d unsupported", d.E);
     T2_REQUIRE(d.kind == 0 || (d.Kc % 2 == 1 && d.F >= 1), "attention_step: bad location layer F=%d Kc=%d", d.F, d.Kc);
     for (int i = 0; i < d.nstreams; ++i)
         T2_REQUIRE(((uintptr_t)d.st[i].pm & 15) == 0 && ((uintptr_t)d.st[i].memory & 15) == 0, "attention_step: pm/memory must be 16-byte aligned");
-    const size_t smem = attention_fwd_smem(d);
+    // LSA: the dense location projection runs on the matrix cores when its [T_in][A] tile fits in LDS beside the rest
+    d.lsa_pa = d.kind == 1 && d.A % 32 == 0 && attention_fwd_smem(d, true) <= 160 * 1024;
+    const size_t smem = attention_fwd_smem(d, d.lsa_pa);
     T2_REQUIRE(smem <= 160 * 1024, "attention_step: T_in too long for LDS (%zu bytes)", smem);
     if (smem > 64 * 1024) {
         T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_step_fwd_kernel),
@@ -691,6 +1051,18 @@ int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s) {
         for (int i = 0; i < d.nstreams; ++i)
             T2_REQUIRE(d.st[i].w && d.st[i].carry_cum && d.st[i].dconv_acc && d.st[i].ddense_acc && d.st[i].loc_conv && d.st[i].loc_dense,
                        "attention_bwd (LSA): missing buffers");
+        const size_t smem_m = (size_t)lsa_mfma_smem(Tmax, d.A, d.E, d.F, d.Kc).total * sizeof(float);
+        if (d.A % 32 == 0 && smem_m <= 160 * 1024 && (Tmax + 31) / 32 + d.A / 32 < NTL / 64) {     // matrix-core variant
+            if (d.A <= 128) {
+                T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_lsa_step_bwd_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m));
+                hipLaunchKernelGGL(attention_lsa_step_bwd_mfma_kernel<2>, dim3(d.B, d.nstreams), dim3(NTL), smem_m, s, d);
+            } else {
+                T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_lsa_step_bwd_mfma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m));
+                hipLaunchKernelGGL(attention_lsa_step_bwd_mfma_kernel<4>, dim3(d.B, d.nstreams), dim3(NTL), smem_m, s, d);
+            }
+            T2_LAUNCH_CHECK();
+            return 0;
+        }
         const size_t smem = (size_t)lsa_bwd_smem(Tmax, d.A, d.E, d.F, d.Kc).total * sizeof(float);
         T2_REQUIRE(smem <= 160 * 1024, "attention_bwd (LSA): T_in=%d too long for LDS (%zu bytes > 160 KiB)", Tmax, smem);
         return d.A <= 128 ? launch_lsa_bwd<2>(d, smem, s) : launch_lsa_bwd<4>(d, smem, s);
