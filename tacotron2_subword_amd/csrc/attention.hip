@@ -13,6 +13,21 @@
 // skipped in the context sum (SMA alignments are sparse early on; 0*x contributes nothing).
 #include "kernels.h"
 
+#ifdef T2_STAMPS
+__device__ unsigned long long t2_stamps_attn[32];
+#define T2_ASTAMP(o, i)                                                                          \
+    do {                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (blockIdx.x == 7 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) t2_stamps_attn[(o) + (i)] = __builtin_amdgcn_s_memrealtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    } while (0)
+extern "C" int t2_debug_read_stamps_attn(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(t2_stamps_attn), sizeof(unsigned long long) * n);
+}
+#else
+#define T2_ASTAMP(o, i)
+#endif
+
 namespace t2 {
 
 namespace {
@@ -37,6 +52,7 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
     const int Tin = st.Tin, A = d.A, E = d.E, F = d.F, Kc = d.Kc;
     const int Tp = (Tin + 3) & ~3;
 
+    T2_ASTAMP(0, 0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* q = smem;                 // [A]
     float* vs = q + A;               // [A]
@@ -47,6 +63,19 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
     float* cred = red + 4 * NT;      // [nh*E]
     const int nd = E / 4, nh = NT / nd;
     float* lsa = cred + nh * E;      // LSA only: convw[F*2*Kc] dense[A*(F+1)] loc[Tin*(F+1)] wpad[2][Tin+Kc-1]
+
+    // Processed-memory rows of the first 2 x NT/16 positions (2 x 64 channels per lane) are requested now: they do
+    // not depend on the query, and the kernel is a chain of dependent L2/MALL round trips
+    constexpr int PFJ = 2, PFA = 2;
+    f32x4 pmv[PFJ][PFA];
+    {
+        const int gid = tid >> 4, sub = tid & 15;
+#pragma unroll
+        for (int i = 0; i < PFJ; ++i)
+#pragma unroll
+            for (int k = 0; k < PFA; ++k)
+                pmv[i][k] = *reinterpret_cast<const f32x4*>(st.pm + ((long)b * Tin + min(gid + i * (NT / 16), Tin - 1)) * A + min(sub * 4 + 64 * k, A - 4));
+    }
 
     // ---- query: direct, or ordered sum of the partials emitted by lstm_step_fwd
     if (st.qpart) {
@@ -141,39 +170,60 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
     }
     __syncthreads();
 
+    T2_ASTAMP(0, 1);
     // ---- energies: 16 lanes per position j
     {
         const int gid = tid >> 4, sub = tid & 15;
-        for (int j = gid; j < Tp; j += NT / 16) {       // Tp keeps whole 16-lane groups converged for the shuffles
-            float sum = 0.f;
-            if (j < Tin) {
-                const float* pmr = st.pm + ((long)b * Tin + j) * A;
-                for (int a = sub * 4; a < A; a += 64) {
-                    f32x4 pv = *reinterpret_cast<const f32x4*>(pmr + a);
+        auto chunk = [&](int j, int a, const f32x4 pv) {      // 4 channels of position j
+            float part = 0.f;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        float u = q[a + c] + pv[c];
-                        if (d.kind == 1) {
-                            if (paS) u += paS[j * PA + a + c];
-                            else {
-                                float pa = 0.f;
-                                const float* dr = dense + (a + c) * F1;
-                                const float* lr = loc + j * F1;
-                                for (int f = 0; f < F; ++f) pa += dr[f] * lr[f];
-                                u += pa;
-                            }
-                        }
-                        sum += vs[a + c] * tanhf(u);
+            for (int c = 0; c < 4; ++c) {
+                float u = q[a + c] + pv[c];
+                if (d.kind == 1) {
+                    if (paS) u += paS[j * PA + a + c];
+                    else {
+                        float pa = 0.f;
+                        const float* dr = dense + (a + c) * F1;
+                        const float* lr = loc + j * F1;
+                        for (int f = 0; f < F; ++f) pa += dr[f] * lr[f];
+                        u += pa;
                     }
                 }
+                part += vs[a + c] * tanhf(u);
             }
+            return part;
+        };
+        auto finish = [&](int j, float sum) {
             sum += __shfl_xor(sum, 8, 64); sum += __shfl_xor(sum, 4, 64);
             sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 1, 64);
             if (sub == 0 && j < Tin) e[j] = sum;
+        };
+#pragma unroll
+        for (int i = 0; i < PFJ; ++i) {                       // prefetched positions (whole 16-lane groups stay converged)
+            const int j = gid + i * (NT / 16);
+            if (j < Tp) {
+                float sum = 0.f;
+                if (j < Tin) {
+#pragma unroll
+                    for (int k = 0; k < PFA; ++k) if (sub * 4 + 64 * k < A) sum += chunk(j, sub * 4 + 64 * k, pmv[i][k]);
+                    const float* pmr = st.pm + ((long)b * Tin + j) * A;
+                    for (int a = sub * 4 + 64 * PFA; a < A; a += 64) sum += chunk(j, a, *reinterpret_cast<const f32x4*>(pmr + a));
+                }
+                finish(j, sum);
+            }
+        }
+        for (int j = gid + PFJ * (NT / 16); j < Tp; j += NT / 16) {
+            float sum = 0.f;
+            if (j < Tin) {
+                const float* pmr = st.pm + ((long)b * Tin + j) * A;
+                for (int a = sub * 4; a < A; a += 64) sum += chunk(j, a, *reinterpret_cast<const f32x4*>(pmr + a));
+            }
+            finish(j, sum);
         }
     }
     __syncthreads();
 
+    T2_ASTAMP(0, 2);
     const int len = st.lengths ? st.lengths[b] : Tin;
     if (d.kind == 0) {
         const RngKey key = rng_key(d.seed, st.site_noise);
@@ -215,6 +265,7 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
     }
     __syncthreads();
 
+    T2_ASTAMP(0, 3);
     // ---- context: nh groups of nd lanes, each lane 4 channels; group h takes j = jlo+h, jlo+h+nh, ...
     // Only the band [jlo, jhi) of non-zero weights is read (an SMA alignment is a narrow band that
     // starts one-hot; exact zeros contribute nothing), with no branch inside the unrolled loop.
@@ -235,6 +286,7 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
             *reinterpret_cast<f32x4*>(cred + h * E + dd) = acc;
         }
         __syncthreads();
+        T2_ASTAMP(0, 4);
         for (int c = tid; c < E; c += NT) {
             float sum = 0.f;
             for (int h2 = 0; h2 < nh; ++h2) sum += cred[h2 * E + c];
@@ -244,6 +296,7 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
             if (st.ctx16b) st.ctx16b[(long)b * st.ldctx16b + c] = (__bf16)sum;
         }
     }
+    T2_ASTAMP(0, 5);
 }
 
 
@@ -280,6 +333,21 @@ __global__ __launch_bounds__(NTB) void attention_step_bwd_kernel(AttnBwdDesc d) 
     float* ps = de + Tp;             // [Tp]
     float* red = ps + Tp;            // [NT/16][A] x 2 (dq, dv partials of the NT/16 position groups)
 
+    T2_ASTAMP(8, 0);
+    // the first batch of memory rows of the g pass (4 positions x 2 x 256 channels per wave) is requested before the
+    // ctx gradient is assembled: the rows do not depend on it
+    constexpr int GU = 4, GC = 2;
+    f32x4 mpre[GC][GU];
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        const int ngp = max((je < Tin ? je - jb + 1 : je - jb), 1);
+#pragma unroll
+        for (int cc = 0; cc < GC; ++cc)
+#pragma unroll
+            for (int u = 0; u < GU; ++u)
+                mpre[cc][u] = *reinterpret_cast<const f32x4*>(st.memory + ((long)b * Tin + min(jb + min(wave + u * (NTB / 64), ngp - 1), Tin - 1)) * E + min(lane * 4 + 256 * cc, E - 4));
+    }
+
     for (int c = tid; c < E; c += NTB) {
         float v = 0.f;
 #pragma unroll
@@ -310,20 +378,25 @@ __global__ __launch_bounds__(NTB) void attention_step_bwd_kernel(AttnBwdDesc d) 
         return;
     }
 
+    T2_ASTAMP(8, 1);
     // g_j: one wave per position, lanes stride the E channels 16 B at a time; 4 positions are in
     // flight per wave so that the row loads overlap instead of serialising on L2 latency
     {
         const int wave = tid >> 6, lane = tid & 63;
         constexpr int NWV = NTB / 64, U = 4;
+        static_assert(U == GU, "prefetch shape");
         for (int j0 = wave; j0 < ng; j0 += NWV * U) {
             float sum[U] = {0.f, 0.f, 0.f, 0.f};
-            for (int c = lane * 4; c < E; c += 256) {
+            int cc = 0;
+            for (int c = lane * 4; c < E; c += 256, ++cc) {
                 const f32x4 dc = *reinterpret_cast<const f32x4*>(dctx + c);
                 f32x4 mv[U];
+                const bool pre = j0 == wave && cc < GC;      // wave-uniform
 #pragma unroll
                 for (int u = 0; u < U; ++u) {           // clamp instead of branching: the U loads issue back to back
                     const int j = jb + min(j0 + u * NWV, ng - 1);
-                    mv[u] = *reinterpret_cast<const f32x4*>(st.memory + ((long)b * Tin + j) * E + c);
+                    if (pre) mv[u] = cc == 0 ? mpre[0][u] : mpre[1][u];
+                    else mv[u] = *reinterpret_cast<const f32x4*>(st.memory + ((long)b * Tin + j) * E + c);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) sum[u] += mv[u][0] * dc[0] + mv[u][1] * dc[1] + mv[u][2] * dc[2] + mv[u][3] * dc[3];
@@ -343,6 +416,7 @@ __global__ __launch_bounds__(NTB) void attention_step_bwd_kernel(AttnBwdDesc d) 
         }
     }
     __syncthreads();
+    T2_ASTAMP(8, 2);
     // carry is read at position je too, which the next split's workgroup updates: the new carry therefore goes to a
     // second buffer (carry / carry_out swap roles every step)
     for (int jl = tid; jl < len; jl += NTB) {
@@ -355,6 +429,7 @@ __global__ __launch_bounds__(NTB) void attention_step_bwd_kernel(AttnBwdDesc d) 
     }
     __syncthreads();
 
+    T2_ASTAMP(8, 3);
     // energies backward: 16 lanes per position, each lane owns channels sub*4 + 64*i
     {
         const int gid = tid >> 4, sub = tid & 15;
@@ -385,6 +460,7 @@ __global__ __launch_bounds__(NTB) void attention_step_bwd_kernel(AttnBwdDesc d) 
                 }
             }
         }
+        T2_ASTAMP(8, 4);
         float* rq = red;
         float* rv = red + (NTB / 16) * A;
 #pragma unroll
@@ -404,6 +480,7 @@ __global__ __launch_bounds__(NTB) void attention_step_bwd_kernel(AttnBwdDesc d) 
             *dvp = (d.first ? 0.f : *dvp) + sv;
         }
     }
+    T2_ASTAMP(8, 5);
 }
 
 // ---------------------------------------------------------------------------------------------
