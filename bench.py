@@ -126,7 +126,7 @@ def side_workload(a, rank, world, local):
     hp.distributed_run = False
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+        dist.init_process_group(backend=os.environ.get("T2_DIST_BACKEND", "nccl"), init_method="env://", world_size=world, rank=rank)
     model = T.load_model(hp)
 
     def sync():
@@ -221,7 +221,7 @@ def main():
     hp.distributed_run = world > 1
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+        dist.init_process_group(backend=os.environ.get("T2_DIST_BACKEND", "nccl"), init_method="env://", world_size=world, rank=rank)
     model, optimizer, criterion = T.make_training_objects(hp)
     model.train()
     B, Tin, Tsub, Tn = a.batch, a.tin, a.tsub, a.frames
