@@ -165,3 +165,41 @@ def test_inference_batch_equals_single_items(env):
             mel, gate, al, alb, flag = O.decoder_inference(mem[i:i + 1], mem_sub[i:i + 1], P, hp, max_decoder_steps=steps, gate_threshold=2.0)
         assert maxabs(dp.mel[i:i + 1].cpu().transpose(1, 2), mel) < TOL
         assert maxabs(dp.align[i:i + 1].cpu(), al) < TOL
+
+
+def _edge_batch(hp, B, Tin, Tsub, T, lens_in, lens_sub):
+    x, y = recipe.parse_batch(recipe.make_batch(hp, B, Tin, Tsub, T, seed=11 * B + T, ragged=False))
+    x = list(x)
+    x[1] = torch.tensor(lens_in, dtype=torch.long)
+    x[2] = torch.tensor(lens_sub, dtype=torch.long)
+    return x
+
+
+@pytest.mark.parametrize("att", [SMA, LSA])
+@pytest.mark.parametrize("case", ["one_frame", "one_position", "length_one_items", "long_memory", "batch_130"])
+def test_teacher_forced_edge_shapes(env, att, case):
+    """Edge shapes of the decoder pass (tiny dims): a single frame, a single memory position, items whose valid
+    length is 1, memories long enough to leave the LDS-resident fast paths (LSA falls back to the scalar location
+    layer), a batch spanning five 32-row tiles."""
+    hp = tiny_hp(att)
+    P = recipe.make_weights(hp, seed=4)
+    if case == "one_frame":
+        B, Tin, Tsub, T, li, ls = 3, 9, 6, 1, [9, 7, 5], [6, 6, 2]
+    elif case == "one_position":
+        B, Tin, Tsub, T, li, ls = 2, 1, 1, 5, [1, 1], [1, 1]
+    elif case == "length_one_items":
+        B, Tin, Tsub, T, li, ls = 3, 10, 8, 6, [10, 1, 1], [8, 1, 3]
+    elif case == "long_memory":
+        B, Tin, Tsub, T, li, ls = 2, 300, 170, 4, [300, 211], [170, 95]
+    else:
+        B, Tin, Tsub, T = 130, 6, 5, 3
+        li, ls = [6] * 100 + [3] * 30, [5] * 90 + [2] * 40
+    x = _edge_batch(hp, B, Tin, Tsub, T, li, ls)
+    mem, mem_sub = oracle_memories(P, hp, x)
+    with torch.no_grad():
+        mel, gate, al, alb = O.decoder_forward(mem, mem_sub, x[3], x[1], x[2], P, hp)
+    dp = run_hip_decoder(env, P, hp, mem, mem_sub, x[1], x[2], x[3])
+    assert maxabs(dp.mel.cpu().transpose(1, 2), mel) < TOL
+    assert maxabs(dp.gate.cpu(), gate) < TOL
+    assert maxabs(dp.align.cpu(), al) < TOL
+    assert maxabs(dp.align_sub.cpu(), alb) < TOL

@@ -38,15 +38,21 @@ def hip_rnd(ops, L, hp, seed, B, T, Tin, Tsub):
                 sma_noise_bert=ops.rng_normal(seed, S["NOISE_SUB"], B * T * Tsub).view(T, B, Tsub).cpu())
 
 
-@pytest.mark.parametrize("cfg", ["tiny_eval", "tiny_train", "tiny_b33", "tiny_long", "tiny_T40", "default_train", "default_align"])
+@pytest.mark.parametrize("cfg", ["tiny_eval", "tiny_train", "tiny_b33", "tiny_long", "tiny_T40", "tiny_one_frame", "tiny_long_memory", "default_train", "default_align"])
 @pytest.mark.parametrize("att", [SMA, LSA])
 def test_decoder_backward_vs_autograd(env, cfg, att):
     L, ops = env
-    training = cfg in ("tiny_train", "default_train", "default_align", "tiny_b33", "tiny_long", "tiny_T40")
+    training = cfg in ("tiny_train", "default_train", "default_align", "tiny_b33", "tiny_long", "tiny_T40", "tiny_long_memory")
     with_align = cfg in ("default_align", "tiny_b33", "tiny_long")
     if cfg == "tiny_long":                       # several 32-position chunks per attention step, ragged tails
         hp = tiny_hp(att)
         B, Tin, Tsub, T = 2, 70, 37, 6
+    elif cfg == "tiny_one_frame":                # T = 1: no recurrent gradient at all
+        hp = tiny_hp(att)
+        B, Tin, Tsub, T = 3, 9, 6, 1
+    elif cfg == "tiny_long_memory":              # memories past the LDS-resident fast paths (LSA: scalar fallback kernel)
+        hp = tiny_hp(att)
+        B, Tin, Tsub, T = 2, 300, 170, 3
     elif cfg == "tiny_T40":                      # long enough for the chunked two-stream schedule (3 chunks of 16 steps)
         hp = tiny_hp(att)
         B, Tin, Tsub, T = 3, 12, 9, 40
@@ -103,14 +109,18 @@ def test_decoder_backward_vs_autograd(env, cfg, att):
     def rel(a, ref):
         return maxabs(a.double(), ref.double()) / max(float(ref.abs().max()), 1e-6)
 
-    # The softmax / sigmoid-recurrence gradients cancel heavily, so even torch's fp32 autograd is only good to a few
-    # 1e-4 on the attention parameters: a tensor passes when it is within RTOL of the fp64 gradient, or no worse than
-    # 3x the fp32 oracle's own rounding error against fp64.
+    # The softmax / sigmoid-recurrence gradients cancel heavily (sum_j de_j = 0 for a softmax), so even torch's fp32
+    # autograd is only good to a few 1e-4 .. 1e-3 on the attention parameters, and which tensor gets the larger error
+    # depends on summation order (scripts/grad_check_case.py).  A tensor passes when it is within RTOL of the fp64
+    # gradient, or no worse than 3x the fp32 oracle's own rounding error against fp64 — for the attention parameters
+    # the oracle's worst error over that group is the yardstick.
     G = dict(G)
     G["d_memory"], G["d_memory_sub"] = dmem, dmems
+    att_noise = max(rel(g32[k], g64[k]) for k in g64 if "attention_layer" in k)
     bad = {}
     for k, ref in g64.items():
-        err, tol = rel(G[k], ref), max(RTOL, 3.0 * rel(g32[k], ref))
+        noise = att_noise if "attention_layer" in k else rel(g32[k], ref)
+        err, tol = rel(G[k], ref), max(RTOL, 3.0 * noise)
         if not err < tol:
             bad[k] = (err, tol)
     assert not bad, bad
