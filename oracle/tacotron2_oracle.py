@@ -420,6 +420,31 @@ def loss(y_pred, y):
     return mel_loss + gate_loss, mel_loss, gate_loss
 
 
+def loss_align(y_pred, y, x, alignloss: str, iters: int = 0):
+    """Tacotron2Loss.forward with the alignment-guide branches (loss_function.py:12-66).  Quirks restated, not fixed:
+    L2 compares both alignments with the phone-level target (:29-31); KL (:32-54) replaces exact zeros by 1e-6,
+    takes mel_len from x[4] = (max_input_len, max_output_len) indexed by batch item, and applies both slices
+    `[:mel_len-1][:text_len-1]` to the frame axis."""
+    total, mel_loss, gate_loss = loss(y_pred, y)
+    al = alb = None
+    if alignloss == "L2" and iters < 40000:
+        al = F.mse_loss(y_pred[3], y[2])
+        alb = F.mse_loss(y_pred[4], y[2])
+    elif alignloss == "KL" and iters < 40000:
+        fix = lambda t: torch.where(t == 0, torch.full_like(t, 0.000001), t)
+        ao, abo, at = fix(y_pred[3]), fix(y_pred[4]), fix(y[2])
+        al = alb = 0
+        for b in range(at.size(0)):
+            n = int(x[4][b]) - 1
+            m = int(x[1][b]) - 1
+            o, ob, t = ao[b][:n][:m], abo[b][:n][:m], at[b][:n][:m]
+            al = al + (t * (t.log() - o.log())).sum(-1).mean()
+            alb = alb + (t * (t.log() - ob.log())).sum(-1).mean()
+    if al is not None:
+        total = total + al + alb
+    return total, mel_loss, gate_loss, al, alb
+
+
 def forward_single(P, hp, x, training: bool = False, rnd=None, new_stats=None):
     """Classic single-stream Tacotron2.forward (the API of GTA.py:57-59): x = (text, text_lengths, mels,
     max_len, output_lengths) -> [mel, mel_postnet, gate, align].  No reference counterpart."""

@@ -248,3 +248,44 @@ def test_bf16_mode_gradients_track_fp32():
             worst[k] = rel
     print("bf16 vs fp32: loss", losses, "worst relative gradient deviations:", dict(sorted(worst.items(), key=lambda kv: -kv[1])[:5]))
     assert not worst, worst
+
+
+@pytest.mark.parametrize("mode", ["L2", "KL"])
+def test_alignment_guide_loss_gradients_reach_the_decoder(mode):
+    """alignloss = L2 / KL (loss_function.py:29-54): the loss is a host reduction on the alignments, its gradient
+    enters the HIP decoder backward through d_align / d_align_sub; whole-model gradients vs the oracle's autograd."""
+    att = SMA
+    hp = hp_for(att)
+    B, Tin, Tsub, T = 2, 10, 10, 12                            # both branches compare BOTH alignments with the phone-level target
+    m, hps = build_model(att, train=False)
+    from tacotron2_subword_amd.loss_function import Tacotron2Loss
+    from tacotron2_subword_amd.utils import Alignment_Generator
+    batch = list(recipe.make_batch(hp, B, Tin, Tsub, T, ragged=False))
+    dur = torch.ones(B, Tin, dtype=torch.long)
+    dur[:, 0] = T - Tin + 1
+    batch[9] = Alignment_Generator()(dur)                      # [B, T, Tin] hard alignment
+    batch = tuple(batch)
+    x, y = m.parse_batch(batch)
+    out = m(x)
+    res = Tacotron2Loss(mode)(out, y, x, 0)
+    res[0].backward()
+    P = recipe.make_weights(hp)
+    for k, v in P.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    xo, yo = recipe.parse_batch(batch)
+    oo = O.forward(P, hp, xo, training=False)
+    ro = O.loss_align(oo, yo, xo, mode, 0)
+    ro[0].backward()
+    for a, b in zip(res, ro):
+        assert abs(float(a.detach()) - float(b.detach())) < 2e-5 * max(1.0, abs(float(b.detach())))
+    bad = {}
+    for k, p in m.named_parameters():
+        ref = P[k].grad
+        if ref is None:
+            assert p.grad is None, k
+            continue
+        err = maxabs(p.grad, ref) / max(float(ref.abs().max()), 1e-7)
+        if not err < 1e-3:
+            bad[k] = err
+    assert not bad, bad
