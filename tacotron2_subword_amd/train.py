@@ -48,6 +48,42 @@ def load_model(hparams):
     return model
 
 
+def warm_start_model(checkpoint_path, model, ignore_layers):
+    """train.py:84-96.  `weights_only=True`: a checkpoint is a dict of tensors / numbers; nothing is unpickled into code."""
+    assert os.path.isfile(checkpoint_path)
+    print("Warm starting model from checkpoint '{}'".format(checkpoint_path))
+    checkpoint_dict = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+    model_dict = checkpoint_dict["state_dict"]
+    if len(ignore_layers) > 0:
+        model_dict = {k: v for k, v in model_dict.items() if k not in ignore_layers}
+        dummy_dict = model.state_dict()
+        dummy_dict.update(model_dict)
+        model_dict = dummy_dict
+    model.load_state_dict(model_dict)
+    return model
+
+
+def load_checkpoint(checkpoint_path, model, optimizer):
+    """train.py:99-112: same dict keys as the reference writes ('state_dict', 'optimizer', 'learning_rate',
+    'iteration', optional 'val_loss'), so its checkpoints load here and vice versa (state_dict keys are unchanged)."""
+    assert os.path.isfile(checkpoint_path)
+    print("Loading checkpoint '{}'".format(checkpoint_path))
+    checkpoint_dict = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+    model.load_state_dict(checkpoint_dict["state_dict"])
+    optimizer.load_state_dict(checkpoint_dict["optimizer"])
+    learning_rate = checkpoint_dict["learning_rate"]
+    iteration = checkpoint_dict["iteration"]
+    print("Loaded checkpoint '{}' from iteration {}".format(checkpoint_path, iteration))
+    return model, optimizer, learning_rate, iteration
+
+
+def save_checkpoint(model, optimizer, learning_rate, iteration, val_loss, filepath):
+    """train.py:115-122."""
+    print("Saving model and optimizer state at iteration {} to {}".format(iteration, filepath))
+    torch.save({"iteration": iteration, "state_dict": model.state_dict(), "optimizer": optimizer.state_dict(),
+                "val_loss": val_loss, "learning_rate": learning_rate}, filepath)
+
+
 def synthetic_batch(hparams, B, Tin=100, Tsub=60, T=400, seed=1234, ragged=True):
     """LJSpeech-shaped phone -> mel batch in the 10-tuple layout parse_batch takes
     (text, input_lengths, input_lengths_bert, mel [B,80,T], gate [B,T], output_lengths, sub_ids,

@@ -80,3 +80,33 @@ def test_synthetic_batch_layout():
         assert (text[i, il[i]:] == 0).all() and (mel[i, :, ol[i]:] == 0).all()
         assert gate[i, ol[i] - 1] == 1 and (gate[i, :ol[i] - 1] == 0).all()
     assert torch.equal(pcls[:, 0], pcls[:, 5])      # one CLS vector repeated along time (data_utils.py:77-78)
+
+
+def test_checkpoint_roundtrip_and_warm_start(tmp_path):
+    """save_checkpoint / load_checkpoint / warm_start_model (train.py:84-122): the reference's dict layout, the
+    reference's state_dict keys (so its checkpoints load unchanged), ignore_layers semantics."""
+    import torch
+    from tacotron2_subword_amd.hparams import create_hparams
+    from tacotron2_subword_amd.model import BERT_Tacotron2
+    from tacotron2_subword_amd import train as T
+    from oracle import recipe, tacotron2_oracle as O
+    hp = create_hparams()
+    m = BERT_Tacotron2(hp)
+    m.load_state_dict(recipe.make_weights(O.default_hparams()))
+    opt = torch.optim.Adam(m.parameters(), lr=hp.learning_rate, weight_decay=hp.weight_decay)
+    path = str(tmp_path / "checkpoint_10")
+    T.save_checkpoint(m, opt, 1e-3, 10, 0.5, path)
+    raw = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(raw) == {"iteration", "state_dict", "optimizer", "val_loss", "learning_rate"}
+    assert list(raw["state_dict"]) == [k for k, _, _ in recipe.state_dict_spec(O.default_hparams())]     # the reference's keys, in order
+    m2 = BERT_Tacotron2(hp)
+    opt2 = torch.optim.Adam(m2.parameters(), lr=1.0)
+    m2, opt2, lr, it = T.load_checkpoint(path, m2, opt2)
+    assert (lr, it) == (1e-3, 10)
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    m3 = BERT_Tacotron2(hp)
+    before = m3.embedding.weight.detach().clone()
+    m3 = T.warm_start_model(path, m3, ["embedding.weight"])        # hparams.ignore_layers default (hparams.py)
+    assert torch.equal(m3.embedding.weight, before)                  # ignored layer keeps its fresh init
+    assert torch.equal(m3.decoder.attention_rnn.weight_ih, m.decoder.attention_rnn.weight_ih)
