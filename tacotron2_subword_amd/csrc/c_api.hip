@@ -65,7 +65,12 @@ static int side_get(Side** out) {
     int dev = 0;
     T2_CHECK_HIP(hipGetDevice(&dev));
     Side& sd = g_side[dev & 15];
-    if (!sd.s) T2_CHECK_HIP(hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking));
+    if (!sd.s) {
+        // lowest priority: chain A (the caller's stream) is the critical path, the side chain has slack
+        int least = 0, greatest = 0;
+        T2_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        T2_CHECK_HIP(hipStreamCreateWithPriority(&sd.s, hipStreamNonBlocking, least));
+    }
     *out = &sd;
     return 0;
 }
