@@ -26,6 +26,8 @@ extern "C" {
 
 #define T2_ATTN_SMA 0 /* StepwiseMonotonicAttention, attention.py:291-398 (hparams default) */
 #define T2_ATTN_LSA 1 /* LocationSensitiveAttention, attention.py:25-85 */
+#define T2_ATTN_FWD2 2 /* ForwardAttentionV2 as model.py drives it (attention.py:87-151 with the never-updated log_alpha of
+                          model.py:266-270,355): LSA energies, softmax over the first two positions; LSA weight layout */
 
 /* RNG sites: a dropout keep-bit / noise sample is a pure function of (seed, site, index). */
 enum {

@@ -212,6 +212,34 @@ def lsa_step(query, memory, pm, w_prev, w_cum, mask, P, prefix, score_mask_value
     return ctx, w
 
 
+def fa2_step(query, memory, pm, w_prev, w_cum, mask, P, prefix, log_alpha):
+    """ForwardAttentionV2.forward (attention.py:128-151) with the log_alpha the caller hands it: model.py:266-270
+    initialises it to [0, -1e4, -1e4, ...] and :355 passes that same tensor at every step (the new log_alpha is
+    commented out of the return, :151), so the 'forward' recursion never advances.  Restated literally."""
+    cat = torch.stack((w_prev, w_cum), dim=1)
+    cw = P[prefix + ".location_layer.location_conv.conv.weight"]
+    loc = F.conv1d(cat, cw, None, padding=(cw.shape[2] - 1) // 2).transpose(1, 2)
+    loc = F.linear(loc, P[prefix + ".location_layer.location_dense.linear_layer.weight"])
+    pq = F.linear(query.unsqueeze(1), P[prefix + ".query_layer.linear_layer.weight"])
+    log_energy = F.linear(torch.tanh(pq + loc + pm), P[prefix + ".v.linear_layer.weight"]).squeeze(-1)
+    score_mask_value = -float(1e20)                                  # attention.py:100
+    if mask is not None:
+        log_energy = log_energy.masked_fill(mask, score_mask_value)
+    shifted = F.pad(log_alpha[:, :-1], [1, 0], "constant", score_mask_value)
+    biased = torch.logsumexp(torch.cat([log_alpha.unsqueeze(2), shifted.unsqueeze(2)], 2), 2)
+    w = F.softmax(biased + log_energy, dim=1)
+    ctx = torch.bmm(w.unsqueeze(1), memory).squeeze(1)
+    return ctx, w
+
+
+def _attend(kind, query, memory, pm, w_prev, w_cum, mask, P, prefix):
+    if kind == "ForwardAttentionV2":
+        la = memory.new_full((memory.shape[0], memory.shape[1]), -float(1e4))
+        la[:, 0] = 0.0
+        return fa2_step(query, memory, pm, w_prev, w_cum, mask, P, prefix, la)
+    return lsa_step(query, memory, pm, w_prev, w_cum, mask, P, prefix)
+
+
 # --------------------------------------------------------------------------------------
 # decoder
 # --------------------------------------------------------------------------------------
@@ -267,8 +295,8 @@ def decode_step(st: DecState, xp: Tensor, xb: Tensor, P, hp, rnd=None, t: int = 
                                       "decoder.attention_layer_bert", _get(rnd, "sma_noise_bert", t))
         st.wb = st.alignb
     else:
-        st.ctx, st.w = lsa_step(st.ah, st.memory, st.pm, st.w, st.wcum, st.mask, P, "decoder.attention_layer")
-        st.ctxb, st.wb = lsa_step(st.ahb, st.memory_sub, st.pmb, st.wb, st.wcumb, st.mask_sub, P,
+        st.ctx, st.w = _attend(hp["attention"], st.ah, st.memory, st.pm, st.w, st.wcum, st.mask, P, "decoder.attention_layer")
+        st.ctxb, st.wb = _attend(hp["attention"], st.ahb, st.memory_sub, st.pmb, st.wb, st.wcumb, st.mask_sub, P,
                                   "decoder.attention_layer_bert")
     st.wcum = st.wcum + st.w
     st.wcumb = st.wcumb + st.wb
@@ -297,7 +325,7 @@ def _decode_step_single(st, P, hp, rnd, t, trace):
         st.ctx, st.align = sma_step(st.ah, st.memory, st.pm, st.align, st.mask, P, "decoder.attention_layer", _get(rnd, "sma_noise", t))
         st.w = st.align
     else:
-        st.ctx, st.w = lsa_step(st.ah, st.memory, st.pm, st.w, st.wcum, st.mask, P, "decoder.attention_layer")
+        st.ctx, st.w = _attend(hp["attention"], st.ah, st.memory, st.pm, st.w, st.wcum, st.mask, P, "decoder.attention_layer")
     st.wcum = st.wcum + st.w
     st.dh, st.dc = lstm_cell(torch.cat((st.ah, st.ctx), -1), st.dh, st.dc,
                              P["decoder.decoder_rnn.weight_ih"], P["decoder.decoder_rnn.weight_hh"],

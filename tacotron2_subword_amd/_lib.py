@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libt2amd.so")
 
-ATTN_SMA, ATTN_LSA = 0, 1
+ATTN_SMA, ATTN_LSA, ATTN_FWD2 = 0, 1, 2
 
 SITE = dict(PRENET1=1, PRENET2=2, PRENET1_SUB=3, PRENET2_SUB=4, ATT_H=5, ATT_C=6, ATT_H_SUB=7, ATT_C_SUB=8,
             DEC_H=9, DEC_C=10, NOISE=11, NOISE_SUB=12, ENC0=16, ENCSUB0=20, POSTNET0=24)
@@ -214,7 +214,7 @@ def stream() -> int:
 
 def dims_from_hparams(hp, n_streams: int = 2) -> Dims:
     g = (lambda k: hp[k]) if isinstance(hp, dict) else (lambda k: getattr(hp, k))
-    kind = ATTN_SMA if g("attention") == "StepwiseMonotonicAttention" else ATTN_LSA
+    kind = {"StepwiseMonotonicAttention": ATTN_SMA, "ForwardAttentionV2": ATTN_FWD2}.get(g("attention"), ATTN_LSA)
     return Dims(int(g("n_mel_channels")) * int(g("n_frames_per_step")), int(g("prenet_dim")), int(g("encoder_embedding_dim")),
                 int(g("attention_rnn_dim")), int(g("decoder_rnn_dim")), int(g("attention_dim")),
                 int(g("attention_location_n_filters")), int(g("attention_location_kernel_size")), kind,

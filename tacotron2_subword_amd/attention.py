@@ -27,6 +27,22 @@ class LocationSensitiveAttention(nn.Module):
         self.score_mask_value = -float("inf")
 
 
+class ForwardAttentionV2(nn.Module):
+    """attention.py:87-151: same parameters as LSA; score_mask_value = -1e20.  As model.py drives it (log_alpha is
+    never updated, model.py:266-270,355) it is the LSA energy followed by a softmax over the first two memory
+    positions — that is what the fused decoder computes for it (T2_ATTN_FWD2)."""
+    kind = "FWD2"
+
+    def __init__(self, attention_rnn_dim, embedding_dim, attention_dim, attention_location_n_filters,
+                 attention_location_kernel_size):
+        super().__init__()
+        self.query_layer = LinearNorm(attention_rnn_dim, attention_dim, bias=False, w_init_gain="tanh")
+        self.memory_layer = LinearNorm(embedding_dim, attention_dim, bias=False, w_init_gain="tanh")
+        self.v = LinearNorm(attention_dim, 1, bias=False)
+        self.location_layer = LocationLayer(attention_location_n_filters, attention_location_kernel_size, attention_dim)
+        self.score_mask_value = -float(1e20)
+
+
 class StepwiseMonotonicAttention(nn.Module):
     kind = "SMA"
 

@@ -224,7 +224,8 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
     __syncthreads();
 
     T2_ASTAMP(0, 2);
-    const int len = st.lengths ? st.lengths[b] : Tin;
+    int len = st.lengths ? st.lengths[b] : Tin;
+    if (d.max_pos > 0) len = min(len, d.max_pos);
     if (d.kind == 0) {
         const RngKey key = rng_key(d.seed, st.site_noise);
         for (int j = tid; j < Tin; j += NT) {

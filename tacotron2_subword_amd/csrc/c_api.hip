@@ -113,8 +113,19 @@ int check_dims(const t2_dims& d) {
     T2_REQUIRE(d.prenet_dim % 64 == 0 && d.enc_dim % 64 == 0 && d.att_rnn_dim % 64 == 0 && d.dec_rnn_dim % 64 == 0,
                "prenet/encoder/rnn dims must be multiples of 64 (got %d %d %d %d)", d.prenet_dim, d.enc_dim, d.att_rnn_dim, d.dec_rnn_dim);
     T2_REQUIRE(d.att_dim % 4 == 0 && d.att_dim <= 256, "attention_dim %d unsupported", d.att_dim);
-    T2_REQUIRE(d.attention_kind == T2_ATTN_SMA || d.attention_kind == T2_ATTN_LSA, "unknown attention kind %d", d.attention_kind);
+    T2_REQUIRE(d.attention_kind == T2_ATTN_SMA || d.attention_kind == T2_ATTN_LSA || d.attention_kind == T2_ATTN_FWD2, "unknown attention kind %d", d.attention_kind);
     return 0;
+}
+
+// ForwardAttentionV2 as the reference runs it (attention.py:87-151; the caller never updates log_alpha, model.py:266-270,
+// 355): log_alpha stays [0, -1e4, -1e4, ...], so the "forward" bias logsumexp(log_alpha_j, log_alpha_{j-1}) is exactly 0
+// for j < 2 and about -1e4 beyond, and softmax(bias + energy) is the LSA softmax over the first two positions with
+// exact zeros elsewhere.  It therefore runs on the LSA kernels with the valid length clamped to 2.
+t2_dims canon_dims(const t2_dims& in, int* max_pos) {
+    t2_dims d = in;
+    *max_pos = 0;
+    if (d.attention_kind == T2_ATTN_FWD2) { d.attention_kind = T2_ATTN_LSA; *max_pos = 2; }
+    return d;
 }
 
 size_t align4(size_t n) { return (n + 3) & ~(size_t)3; }
@@ -177,6 +188,7 @@ struct Dec {
     bool training; bool prenet_dropout; bool teacher; uint64_t seed; hipStream_t s;
     bool use16 = false;                              // bf16-operand recurrent steps (t2_set_precision(1))
     hipStream_t sd = nullptr;                        // stream of the decoder-LSTM chain (== s unless overlapped)
+    int max_pos = 0;                                 // > 0: attention restricted to the first max_pos positions (ForwardAttentionV2)
     InferShadows I{};                                // decode loop only (teacher == false && use16)
     __bf16* RowA(int parity, int s) const { return reinterpret_cast<__bf16*>(ws + I.rows_a) + (size_t)(parity * 2 + s) * z.B * I.Ka; }
     __bf16* RowD(int parity) const { return reinterpret_cast<__bf16*>(ws + I.rows_d) + (size_t)parity * z.B * I.Kd; }
@@ -290,6 +302,7 @@ int attention_step(const Dec& c, int t) {
     d.F = c.d.loc_filters; d.Kc = c.d.loc_kernel; d.seed = c.seed; d.first = t == 0;
     d.noise_std = (c.training && d.kind == T2_ATTN_SMA) ? 2.0f : 0.f;     // attention.py:315,346-348
     d.mask_value = -INFINITY;                                              // attention.py:37,306
+    d.max_pos = c.max_pos;
     for (int s = 0; s < z.NS; ++s) {
         AttnStream& st = d.st[s];
         const t2_attention_weights& aw = s ? c.w.attn_sub : c.w.attn;
@@ -587,23 +600,32 @@ int t2_set_precision(int mode) {
 int t2_get_precision(void) { return get_precision(); }
 int t2_set_overlap(int on) { g_overlap = on != 0; return 0; }
 
-int t2_decoder_layout_query(const t2_dims* dims, int B, int T, int Tin, int Tsub, t2_decoder_layout* out) {
-    T2_REQUIRE(dims && out, "null argument");
-    T2_TRY(check_dims(*dims));
+int t2_decoder_layout_query(const t2_dims* dims_in, int B, int T, int Tin, int Tsub, t2_decoder_layout* out) {
+    T2_REQUIRE(dims_in && out, "null argument");
+    T2_TRY(check_dims(*dims_in));
+    int max_pos = 0;
+    const t2_dims dd = canon_dims(*dims_in, &max_pos);
+    const t2_dims* dims = &dd;
+    (void)max_pos;
     T2_REQUIRE(B >= 1 && B <= 256 && T >= 1 && Tin >= 1 && Tsub >= 1, "bad shape B=%d T=%d Tin=%d Tsub=%d", B, T, Tin, Tsub);
     layout_of(*dims, sizes_of(*dims, B, T, Tin, Tsub), out);
     return 0;
 }
 
-int t2_decoder_forward(const t2_dims* dims, const t2_decoder_weights* w, const t2_decoder_fwd_args* a, void* stream) {
-    T2_REQUIRE(dims && w && a, "null argument");
-    T2_TRY(check_dims(*dims));
+int t2_decoder_forward(const t2_dims* dims_in, const t2_decoder_weights* w, const t2_decoder_fwd_args* a, void* stream) {
+    T2_REQUIRE(dims_in && w && a, "null argument");
+    T2_TRY(check_dims(*dims_in));
+    int max_pos = 0;
+    const t2_dims dd = canon_dims(*dims_in, &max_pos);
+    const t2_dims* dims = &dd;
+    (void)max_pos;
     T2_REQUIRE(a->B >= 1 && a->B <= 256 && a->T >= 1, "bad shape B=%d T=%d", a->B, a->T);
     T2_REQUIRE((long)a->B * a->T * 4 * dims->att_rnn_dim < (1l << 32), "B*T too large for 32-bit RNG indices");
     Dec c{*dims, *w, sizes_of(*dims, a->B, a->T, a->Tin, a->Tsub), {}, a->ws,
           a->memory, a->memory_sub, a->mem_lengths, a->sub_lengths,
           a->mel_out, a->gate_out, a->align, a->align_sub,
           a->training != 0, a->prenet_dropout != 0, true, a->seed, (hipStream_t)stream};
+    c.max_pos = max_pos;
     layout_of(*dims, c.z, &c.L);
     const Sizes& z = c.z; const t2_decoder_layout& L = c.L;
     const int BT = z.B * z.T;
@@ -651,18 +673,26 @@ int t2_decoder_forward(const t2_dims* dims, const t2_decoder_weights* w, const t
 }
 
 
-int t2_decoder_bwd_layout_query(const t2_dims* dims, int B, int T, int Tin, int Tsub, t2_decoder_bwd_layout* out) {
-    T2_REQUIRE(dims && out, "null argument");
-    T2_TRY(check_dims(*dims));
+int t2_decoder_bwd_layout_query(const t2_dims* dims_in, int B, int T, int Tin, int Tsub, t2_decoder_bwd_layout* out) {
+    T2_REQUIRE(dims_in && out, "null argument");
+    T2_TRY(check_dims(*dims_in));
+    int max_pos = 0;
+    const t2_dims dd = canon_dims(*dims_in, &max_pos);
+    const t2_dims* dims = &dd;
+    (void)max_pos;
     T2_REQUIRE(B >= 1 && B <= 256 && T >= 1 && Tin >= 1 && Tsub >= 1, "bad shape B=%d T=%d Tin=%d Tsub=%d", B, T, Tin, Tsub);
     bwd_layout_of(*dims, sizes_of(*dims, B, T, Tin, Tsub), out);
     return 0;
 }
 
-int t2_decoder_backward(const t2_dims* dims, const t2_decoder_weights* w, const t2_decoder_grads* g,
+int t2_decoder_backward(const t2_dims* dims_in, const t2_decoder_weights* w, const t2_decoder_grads* g,
                         const t2_decoder_bwd_args* a, void* stream) {
-    T2_REQUIRE(dims && w && g && a, "null argument");
-    T2_TRY(check_dims(*dims));
+    T2_REQUIRE(dims_in && w && g && a, "null argument");
+    T2_TRY(check_dims(*dims_in));
+    int max_pos = 0;
+    const t2_dims dd = canon_dims(*dims_in, &max_pos);
+    const t2_dims* dims = &dd;
+    (void)max_pos;
     Bwd c{*dims, *w, *g, *a, sizes_of(*dims, a->B, a->T, a->Tin, a->Tsub), {}, {}, (hipStream_t)stream};
     layout_of(*dims, c.z, &c.L);
     bwd_layout_of(*dims, c.z, &c.BL);
@@ -780,14 +810,19 @@ int t2_decoder_backward(const t2_dims* dims, const t2_decoder_weights* w, const 
     return 0;
 }
 
-int t2_decoder_infer(const t2_dims* dims, const t2_decoder_weights* w, const t2_decoder_infer_args* a, void* stream) {
-    T2_REQUIRE(dims && w && a && a->steps_run_host, "null argument");
-    T2_TRY(check_dims(*dims));
+int t2_decoder_infer(const t2_dims* dims_in, const t2_decoder_weights* w, const t2_decoder_infer_args* a, void* stream) {
+    T2_REQUIRE(dims_in && w && a && a->steps_run_host, "null argument");
+    T2_TRY(check_dims(*dims_in));
+    int max_pos = 0;
+    const t2_dims dd = canon_dims(*dims_in, &max_pos);
+    const t2_dims* dims = &dd;
+    (void)max_pos;
     T2_REQUIRE(a->B >= 1 && a->B <= 256 && a->max_steps >= 1, "bad shape B=%d max_steps=%d", a->B, a->max_steps);
     Dec c{*dims, *w, sizes_of(*dims, a->B, a->max_steps, a->Tin, a->Tsub), {}, a->ws,
           a->memory, a->memory_sub, a->mem_lengths, a->sub_lengths,
           a->mel_out, a->gate_out, a->align, a->align_sub,
           false, a->prenet_dropout != 0, false, a->seed, (hipStream_t)stream};
+    c.max_pos = max_pos;
     layout_of(*dims, c.z, &c.L);
     const Sizes& z = c.z; const t2_decoder_layout& L = c.L;
     const int T = z.T;

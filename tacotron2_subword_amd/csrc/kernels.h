@@ -121,6 +121,7 @@ struct AttnStepDesc {
     AttnStream st[2]; int nstreams; int B, A, E; int kind;   // kind 0 = SMA, 1 = LSA
     int F, Kc; float noise_std; uint64_t seed; float mask_value; int first;
     int lsa_pa;                                               // set by the launcher (MFMA path of the LSA dense projection)
+    int max_pos;                                              // > 0: valid length clamped to max_pos (ForwardAttentionV2, see c_api.hip)
 };
 int attention_step_fwd(const AttnStepDesc& d, hipStream_t s);
 

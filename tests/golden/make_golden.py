@@ -96,7 +96,10 @@ def build_reference(ref_model, ref_attention, ref_hparams, attention, seed=1234)
     hps.attention = attention
     m = ref_model.BERT_Tacotron2(hps)
     if attention != "StepwiseMonotonicAttention":
-        m.decoder.attention_layer_bert = ref_attention.LocationSensitiveAttention(
+        # model.py:158-191 builds attention_layer_bert only for SMA and then uses it unconditionally (:261,356): the
+        # harness supplies the missing module of the same class
+        cls = ref_attention.ForwardAttentionV2 if attention == "ForwardAttentionV2" else ref_attention.LocationSensitiveAttention
+        m.decoder.attention_layer_bert = cls(
             hps.attention_rnn_dim, hps.encoder_embedding_dim, hps.attention_dim,
             hps.attention_location_n_filters, hps.attention_location_kernel_size)
     hp = O.default_hparams()
@@ -253,7 +256,20 @@ def main():
     gen_forward(refs, SMA, "sma_baseline_eval", 2, 100, 60, 400, training=False, steps_to_keep=(0, 199, -1))
     gen_inference(refs, SMA, "sma_infer", 21, 11)
     gen_inference(refs, LSA, "lsa_infer", 21, 11)
+    gen_fa2(refs)
+
+
+def gen_fa2(refs):
+    """ForwardAttentionV2 — added after the first fixtures; `python make_golden.py fa2` writes only these."""
+    FA2 = "ForwardAttentionV2"
+    gen_forward(refs, FA2, "fa2_small_eval", 2, 13, 8, 12, training=False)
+    gen_forward(refs, FA2, "fa2_small_train", 3, 13, 8, 12, training=True, with_grads=True)
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["fa2"]:
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        gen_fa2(import_reference())
+    else:
+        main()

@@ -9,7 +9,7 @@ import torch
 from oracle import recipe
 from oracle import tacotron2_oracle as O
 
-from helpers import LSA, SMA, hp_for, maxabs, oracle_memories, tiny_hp, to_dev
+from helpers import FA2, LSA, SMA, hp_for, maxabs, oracle_memories, tiny_hp, to_dev
 
 pytestmark = pytest.mark.gpu
 RTOL = 3e-4          # max-abs error relative to the largest reference entry of each gradient tensor
@@ -39,7 +39,7 @@ def hip_rnd(ops, L, hp, seed, B, T, Tin, Tsub):
 
 
 @pytest.mark.parametrize("cfg", ["tiny_eval", "tiny_train", "tiny_b33", "tiny_long", "tiny_T40", "tiny_one_frame", "tiny_long_memory", "default_train", "default_align"])
-@pytest.mark.parametrize("att", [SMA, LSA])
+@pytest.mark.parametrize("att", [SMA, LSA, FA2])
 def test_decoder_backward_vs_autograd(env, cfg, att):
     L, ops = env
     training = cfg in ("tiny_train", "default_train", "default_align", "tiny_b33", "tiny_long", "tiny_T40", "tiny_long_memory")
