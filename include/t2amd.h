@@ -26,6 +26,7 @@ extern "C" {
 
 #define T2_ATTN_SMA 0 /* StepwiseMonotonicAttention, attention.py:291-398 (hparams default) */
 #define T2_ATTN_LSA 1 /* LocationSensitiveAttention, attention.py:25-85 */
+#define T2_ATTN_GMM 3  /* GMMAttention version '2', K = 5 (attention.py:401-506) */
 #define T2_ATTN_FWD2 2 /* ForwardAttentionV2 as model.py drives it (attention.py:87-151 with the never-updated log_alpha of
                           model.py:266-270,355): LSA energies, softmax over the first two positions; LSA weight layout */
 
@@ -74,6 +75,10 @@ typedef struct t2_attention_weights {
     const float* v;         /* v.weight | v.linear_layer.weight       [1, A] */
     const float* loc_conv;  /* location_layer.location_conv.conv.weight   [F,2,Kc] (LSA) */
     const float* loc_dense; /* location_layer.location_dense.linear_layer.weight [A,F] (LSA) */
+    /* GMMAttention (T2_ATTN_GMM): wq = mlp.0.weight [A, att_rnn]; wm exists in the state_dict but is not used */
+    const float* mlp_b1;    /* mlp.0.bias   [A] */
+    const float* mlp_w2;    /* mlp.2.weight [15, A] */
+    const float* mlp_b2;    /* mlp.2.bias   [15] */
 } t2_attention_weights;
 typedef struct t2_lstm_weights { const float *w_ih, *w_hh, *b_ih, *b_hh; } t2_lstm_weights;
 typedef struct t2_decoder_weights {
@@ -98,7 +103,7 @@ typedef struct t2_decoder_layout {
     size_t cna, cnas, ca, cas;        /* cell before / after dropout [T,B,Ha] */
     size_t din;                       /* [T,B, 2*Ha+2*E] = att_h | ctx | att_h_sub | ctx_sub */
     size_t psel, psels;               /* SMA p_t [B,T,Tin], [B,T,Tsub] */
-    size_t wcum, wcums;               /* LSA cumulative weights per step [B,T,Tin], [B,T,Tsub] */
+    size_t wcum, wcums;               /* LSA cumulative weights per step [B,T,Tin], [B,T,Tsub]; GMM: mixture means [T,B,8] */
     size_t pred, gd, cnd, cd;         /* decoder LSTM: pre-activations, gates [T,B,4*Hd], cells [T,B,Hd] */
     size_t dout;                      /* [T,B, Hd+2*E] = dec_h | ctx | ctx_sub */
     size_t qs, qss;                   /* processed query per step [T,B,A] */
@@ -137,7 +142,7 @@ int t2_decoder_forward(const t2_dims* dims, const t2_decoder_weights* w, const t
  * weights; d_memory / d_memory_sub receive the gradient wrt the encoder memories.
  * Both attention kinds; for LSA the location-layer gradient pointers of t2_attention_grads must be set. */
 typedef struct t2_lstm_grads { float *w_ih, *w_hh, *b_ih, *b_hh; } t2_lstm_grads;
-typedef struct t2_attention_grads { float *wq, *wm, *v, *loc_conv, *loc_dense; } t2_attention_grads;
+typedef struct t2_attention_grads { float *wq, *wm, *v, *loc_conv, *loc_dense, *mlp_b1, *mlp_w2, *mlp_b2; } t2_attention_grads;
 typedef struct t2_decoder_grads {
     float *prenet_w1, *prenet_w2, *prenet_sub_w1, *prenet_sub_w2;
     t2_lstm_grads att, att_sub;
@@ -148,7 +153,7 @@ typedef struct t2_decoder_grads {
 typedef struct t2_decoder_bwd_layout {
     size_t total_floats;
     size_t ddout, ddin, dgd, dga, dgas, dctx, dctxs, dq, dqs, dv, dvs, dpm, dpms, carry, carrys;
-    size_t carryc, carrycs, dlconv, dlconvs, dldense, dldenses;   /* LSA only (zero-sized for SMA) */
+    size_t carryc, carrycs, dlconv, dlconvs, dldense, dldenses;   /* LSA: cumulative carry, per-item location-layer gradients; GMM: mean carry, per-item db2 / dW2; zero-sized for SMA */
     size_t dcd, dca, dcas, partd, parta, dp2, dp2s, dp1, dmel_t, dgate_t, dg16a, dg16d, colsum_ws, gemm_ws, gemm_ws_floats;
 } t2_decoder_bwd_layout;
 int t2_decoder_bwd_layout_query(const t2_dims* dims, int B, int T, int Tin, int Tsub, t2_decoder_bwd_layout* out);

@@ -57,6 +57,10 @@ def state_dict_spec(hp: dict) -> List[Tuple[str, Tuple[int, ...], str]]:
             add(prefix + ".memory_layer.linear_layer.weight", (A, E), "linear")
             add(prefix + ".v.weight", (1, A), "linear")
             add(prefix + ".query_layer.linear_layer.weight", (A, Ha), "linear")
+        elif hp["attention"] == "GMMAttention":                      # attention.py:405-415
+            add(prefix + ".memory_layer.linear_layer.weight", (A, E), "linear")
+            add(prefix + ".mlp.0.weight", (A, Ha), "linear"); add(prefix + ".mlp.0.bias", (A,), "bias")
+            add(prefix + ".mlp.2.weight", (15, A), "linear"); add(prefix + ".mlp.2.bias", (15,), "bias")
         else:                                                        # LSA, attention.py:26-37
             add(prefix + ".query_layer.linear_layer.weight", (A, Ha), "linear")
             add(prefix + ".memory_layer.linear_layer.weight", (A, E), "linear")

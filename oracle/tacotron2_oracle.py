@@ -232,7 +232,34 @@ def fa2_step(query, memory, pm, w_prev, w_cum, mask, P, prefix, log_alpha):
     return ctx, w
 
 
-def _attend(kind, query, memory, pm, w_prev, w_cum, mask, P, prefix):
+def gmm_step(query, memory, mu_prev, mask, P, prefix):
+    """GMMAttention.forward, version '2', K = 5 (attention.py:427-506).  mu_prev: [B,K,1] (init_attention: zeros)."""
+    K, eps = 5, 1e-5
+    hid = torch.tanh(F.linear(query, P[prefix + ".mlp.0.weight"], P[prefix + ".mlp.0.bias"]))
+    interm = F.linear(hid, P[prefix + ".mlp.2.weight"], P[prefix + ".mlp.2.bias"]).view(query.size(0), -1, K)
+    omega_hat, delta_hat, sigma_hat = (c.squeeze(1) for c in interm.chunk(3, dim=1))
+    sigma = (F.softplus(sigma_hat) + eps).unsqueeze(-1)
+    delta = F.softplus(delta_hat).unsqueeze(-1)
+    omega = F.softmax(omega_hat, dim=-1).unsqueeze(-1)
+    Z = torch.sqrt(2 * math.pi * sigma ** 2)
+    mu = mu_prev + delta
+    j = torch.arange(0, memory.size(1), device=memory.device).view(1, 1, -1)
+    alignment = torch.sum(omega / Z * torch.exp(-(j - mu) ** 2 / (sigma ** 2) / 2), 1)
+    if mask is not None:
+        alignment = alignment.masked_fill(mask, -float("inf"))
+    w = F.softmax(alignment, dim=1)
+    ctx = torch.bmm(w.unsqueeze(1), memory).squeeze(1)
+    return ctx, w, mu
+
+
+def _attend(kind, query, memory, pm, w_prev, w_cum, mask, P, prefix, st=None):
+    if kind == "GMMAttention":
+        key = "mu_" + prefix
+        mu_prev = st.gmm.get(key)
+        if mu_prev is None:
+            mu_prev = memory.new_zeros(memory.shape[0], 5, 1)
+        ctx, w, st.gmm[key] = gmm_step(query, memory, mu_prev, mask, P, prefix)
+        return ctx, w
     if kind == "ForwardAttentionV2":
         la = memory.new_full((memory.shape[0], memory.shape[1]), -float(1e4))
         la[:, 0] = 0.0
@@ -264,6 +291,7 @@ class DecState:
         self.pm = F.linear(memory, P["decoder.attention_layer.memory_layer.linear_layer.weight"])
         self.pmb = None if self.single else F.linear(memory_sub, P["decoder.attention_layer_bert.memory_layer.linear_layer.weight"])
         self.mask, self.mask_sub = mask, mask_sub
+        self.gmm = {}                               # GMMAttention: mixture means per attention module (init_attention: zeros)
         self.sma = hp["attention"] == "StepwiseMonotonicAttention"
         if self.sma:                                # attention.py:324-328
             self.align = z(B, Tin); self.align[:, 0] = 1.0
@@ -295,9 +323,9 @@ def decode_step(st: DecState, xp: Tensor, xb: Tensor, P, hp, rnd=None, t: int = 
                                       "decoder.attention_layer_bert", _get(rnd, "sma_noise_bert", t))
         st.wb = st.alignb
     else:
-        st.ctx, st.w = _attend(hp["attention"], st.ah, st.memory, st.pm, st.w, st.wcum, st.mask, P, "decoder.attention_layer")
+        st.ctx, st.w = _attend(hp["attention"], st.ah, st.memory, st.pm, st.w, st.wcum, st.mask, P, "decoder.attention_layer", st)
         st.ctxb, st.wb = _attend(hp["attention"], st.ahb, st.memory_sub, st.pmb, st.wb, st.wcumb, st.mask_sub, P,
-                                  "decoder.attention_layer_bert")
+                                  "decoder.attention_layer_bert", st)
     st.wcum = st.wcum + st.w
     st.wcumb = st.wcumb + st.wb
     # decoder LSTM (model.py:362-373)
@@ -325,7 +353,7 @@ def _decode_step_single(st, P, hp, rnd, t, trace):
         st.ctx, st.align = sma_step(st.ah, st.memory, st.pm, st.align, st.mask, P, "decoder.attention_layer", _get(rnd, "sma_noise", t))
         st.w = st.align
     else:
-        st.ctx, st.w = _attend(hp["attention"], st.ah, st.memory, st.pm, st.w, st.wcum, st.mask, P, "decoder.attention_layer")
+        st.ctx, st.w = _attend(hp["attention"], st.ah, st.memory, st.pm, st.w, st.wcum, st.mask, P, "decoder.attention_layer", st)
     st.wcum = st.wcum + st.w
     st.dh, st.dc = lstm_cell(torch.cat((st.ah, st.ctx), -1), st.dh, st.dc,
                              P["decoder.decoder_rnn.weight_ih"], P["decoder.decoder_rnn.weight_hh"],

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libt2amd.so")
 
-ATTN_SMA, ATTN_LSA, ATTN_FWD2 = 0, 1, 2
+ATTN_SMA, ATTN_LSA, ATTN_FWD2, ATTN_GMM = 0, 1, 2, 3
 
 SITE = dict(PRENET1=1, PRENET2=2, PRENET1_SUB=3, PRENET2_SUB=4, ATT_H=5, ATT_C=6, ATT_H_SUB=7, ATT_C_SUB=8,
             DEC_H=9, DEC_C=10, NOISE=11, NOISE_SUB=12, ENC0=16, ENCSUB0=20, POSTNET0=24)
@@ -31,7 +31,8 @@ class Dims(C.Structure):
 
 
 class AttentionWeights(C.Structure):
-    _fields_ = [("wq", C.c_void_p), ("wm", C.c_void_p), ("v", C.c_void_p), ("loc_conv", C.c_void_p), ("loc_dense", C.c_void_p)]
+    _fields_ = [("wq", C.c_void_p), ("wm", C.c_void_p), ("v", C.c_void_p), ("loc_conv", C.c_void_p), ("loc_dense", C.c_void_p),
+                ("mlp_b1", C.c_void_p), ("mlp_w2", C.c_void_p), ("mlp_b2", C.c_void_p)]
 
 
 class LstmWeights(C.Structure):
@@ -214,7 +215,7 @@ def stream() -> int:
 
 def dims_from_hparams(hp, n_streams: int = 2) -> Dims:
     g = (lambda k: hp[k]) if isinstance(hp, dict) else (lambda k: getattr(hp, k))
-    kind = {"StepwiseMonotonicAttention": ATTN_SMA, "ForwardAttentionV2": ATTN_FWD2}.get(g("attention"), ATTN_LSA)
+    kind = {"StepwiseMonotonicAttention": ATTN_SMA, "ForwardAttentionV2": ATTN_FWD2, "GMMAttention": ATTN_GMM}.get(g("attention"), ATTN_LSA)
     return Dims(int(g("n_mel_channels")) * int(g("n_frames_per_step")), int(g("prenet_dim")), int(g("encoder_embedding_dim")),
                 int(g("attention_rnn_dim")), int(g("decoder_rnn_dim")), int(g("attention_dim")),
                 int(g("attention_location_n_filters")), int(g("attention_location_kernel_size")), kind,
@@ -231,10 +232,13 @@ def decoder_weights(P: dict, kind: int, prefix: str = "decoder.", single: bool =
         if kind == ATTN_SMA:
             return AttentionWeights(p(n + ".query_layer.linear_layer.weight"), p(n + ".memory_layer.linear_layer.weight"),
                                     p(n + ".v.weight"), None, None)
+        if kind == ATTN_GMM:       # mlp.0 plays the part of the query projection (attention.py:412-415)
+            return AttentionWeights(p(n + ".mlp.0.weight"), None, None, None, None,       # memory_layer is never read
+                                    p(n + ".mlp.0.bias"), p(n + ".mlp.2.weight"), p(n + ".mlp.2.bias"))
         return AttentionWeights(p(n + ".query_layer.linear_layer.weight"), p(n + ".memory_layer.linear_layer.weight"),
                                 p(n + ".v.linear_layer.weight"), p(n + ".location_layer.location_conv.conv.weight"),
                                 p(n + ".location_layer.location_dense.linear_layer.weight"))
-    none_l, none_a = LstmWeights(None, None, None, None), AttentionWeights(None, None, None, None, None)
+    none_l, none_a = LstmWeights(None, None, None, None), AttentionWeights()
     return DecoderWeights(p("prenet.layers.0.linear_layer.weight"), p("prenet.layers.1.linear_layer.weight"),
                           None if single else p("prenet_bert.layers.0.linear_layer.weight"),
                           None if single else p("prenet_bert.layers.1.linear_layer.weight"),
@@ -272,8 +276,25 @@ def _lsa_keys():
 DECODER_PARAM_KEYS_LSA = _lsa_keys()
 
 
+def _gmm_keys():
+    """Parameters that receive a gradient with GMMAttention: its memory_layer does not (never used, attention.py:401-506)."""
+    out = []
+    for k in DECODER_PARAM_KEYS_SMA:
+        if ".query_layer." in k:
+            n = k[:k.index(".query_layer.")]
+            out += [n + ".mlp.0.weight", n + ".mlp.0.bias", n + ".mlp.2.weight", n + ".mlp.2.bias"]
+        elif ".memory_layer." in k or k.endswith(".v.weight"):
+            continue
+        else:
+            out.append(k)
+    return out
+
+
+DECODER_PARAM_KEYS_GMM = _gmm_keys()
+
+
 def decoder_param_keys(kind: int, single: bool = False):
-    keys = DECODER_PARAM_KEYS_SMA if kind == ATTN_SMA else DECODER_PARAM_KEYS_LSA
+    keys = DECODER_PARAM_KEYS_SMA if kind == ATTN_SMA else DECODER_PARAM_KEYS_GMM if kind == ATTN_GMM else DECODER_PARAM_KEYS_LSA
     return [k for k in keys if "_bert" not in k] if single else keys
 
 
@@ -286,10 +307,13 @@ def decoder_grads(G: dict, prefix: str = "decoder.", single: bool = False, kind:
         if kind == ATTN_SMA:
             return AttentionGrads(p(n + ".query_layer.linear_layer.weight"), p(n + ".memory_layer.linear_layer.weight"),
                                   p(n + ".v.weight"), None, None)
+        if kind == ATTN_GMM:
+            return AttentionGrads(p(n + ".mlp.0.weight"), None, None, None, None,
+                                  p(n + ".mlp.0.bias"), p(n + ".mlp.2.weight"), p(n + ".mlp.2.bias"))
         return AttentionGrads(p(n + ".query_layer.linear_layer.weight"), p(n + ".memory_layer.linear_layer.weight"),
                               p(n + ".v.linear_layer.weight"), p(n + ".location_layer.location_conv.conv.weight"),
                               p(n + ".location_layer.location_dense.linear_layer.weight"))
-    none_l, none_a = LstmGrads(None, None, None, None), AttentionGrads(None, None, None, None, None)
+    none_l, none_a = LstmGrads(None, None, None, None), AttentionGrads()
     return DecoderGrads(p("prenet.layers.0.linear_layer.weight"), p("prenet.layers.1.linear_layer.weight"),
                         None if single else p("prenet_bert.layers.0.linear_layer.weight"),
                         None if single else p("prenet_bert.layers.1.linear_layer.weight"),

@@ -43,6 +43,23 @@ class ForwardAttentionV2(nn.Module):
         self.score_mask_value = -float(1e20)
 
 
+class GMMAttention(nn.Module):
+    """attention.py:401-506 (version '2', K = 5): purely location-based mixture attention.  memory_layer exists (and
+    is in the state_dict) but takes no part in the arithmetic, so it never receives a gradient."""
+    kind = "GMM"
+
+    def __init__(self, attention_rnn_dim, embedding_dim, attention_dim, attention_location_n_filters,
+                 attention_location_kernel_size, version="2"):
+        super().__init__()
+        if version != "2":
+            raise NotImplementedError("GMMAttention: only version '2' (the reference's default) is built")
+        self.memory_layer = LinearNorm(embedding_dim, attention_dim, bias=False, w_init_gain="tanh")
+        self.score_mask_value = -float("inf")
+        self.gmm_version, self.K, self.eps = version, 5, 1e-5
+        self.mlp = nn.Sequential(nn.Linear(attention_rnn_dim, attention_dim, bias=True), nn.Tanh(),
+                                 nn.Linear(attention_dim, 3 * self.K))
+
+
 class StepwiseMonotonicAttention(nn.Module):
     kind = "SMA"
 

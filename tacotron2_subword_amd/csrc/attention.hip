@@ -1072,6 +1072,278 @@ __global__ __launch_bounds__(NTL) void attention_lsa_step_bwd_mfma_kernel(AttnBw
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// GMMAttention, version '2' (attention.py:401-506): purely location-based.
+//   hid = tanh(W1 h + b1) ; [omega^, delta^, sigma^] = W2 hid + b2            (3 x K, K = 5)
+//   sigma = softplus(sigma^) + 1e-5 ; delta = softplus(delta^) ; omega = softmax(omega^) ; Z = sqrt(2 pi sigma^2)
+//   mu_t = mu_{t-1} + delta ; phi_j = sum_k omega_k / Z_k exp(-(j - mu_k)^2 / sigma_k^2 / 2)
+//   w = softmax(mask(phi)) ; ctx = w . memory
+// W1 h arrives as the ordered partials of the LSTM step kernel (the same path as the query projection of the other
+// attention kinds), so only the tiny second layer runs here.  One workgroup per (b, stream).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.f ? x : log1pf(expf(x)); }      // torch's threshold
+
+struct GmmPar { float omega[kGmmK], sigma[kGmmK], delta[kGmmK], Z[kGmmK]; };
+// ip: [3K] = omega^ | delta^ | sigma^ (interm_params.view(B, 3, K), attention.py:437-443)
+__device__ __forceinline__ GmmPar gmm_params(const float* ip) {
+    GmmPar p;
+    float mx = -INFINITY, sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < kGmmK; ++k) mx = fmaxf(mx, ip[k]);
+#pragma unroll
+    for (int k = 0; k < kGmmK; ++k) { p.omega[k] = expf(ip[k] - mx); sum += p.omega[k]; }
+#pragma unroll
+    for (int k = 0; k < kGmmK; ++k) {
+        p.omega[k] /= sum;
+        p.delta[k] = softplusf_(ip[kGmmK + k]);
+        p.sigma[k] = softplusf_(ip[2 * kGmmK + k]) + 1e-5f;
+        p.Z[k] = sqrtf(2.0f * 3.14159265358979323846f * p.sigma[k] * p.sigma[k]);
+    }
+    return p;
+}
+
+__global__ __launch_bounds__(NT) void attention_gmm_step_fwd_kernel(AttnStepDesc d) {
+    const AttnStream& st = d.st[blockIdx.y];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int Tin = st.Tin, A = d.A, E = d.E;
+    const int Tp = (Tin + 3) & ~3;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* hid = smem;               // [A]
+    float* e = hid + A;              // [Tp]
+    float* an = e + Tp;              // [Tp]
+    float* red = an + Tp;            // [4*NT]
+    const int nd = E / 4, nh = NT / nd;
+    float* cred = red + 4 * NT;      // [nh*E]
+    float* ip = cred + nh * E;       // [16]
+    float* par = ip + 16;            // [4][8]: c = omega/Z, mu, sigma^2
+
+    // ---- first MLP layer: ordered sum of the partials + bias, tanh
+    {
+        const int a4n = A / 4, ng = NT / a4n;
+        const int pg = tid / a4n, a4 = (tid % a4n) * 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* p = st.qpart + (long)b * A + a4;
+        const long ps = (long)d.B * A;
+#pragma unroll 4
+        for (int i = pg; i < st.nparts; i += ng) acc += *reinterpret_cast<const f32x4*>(p + (long)i * ps);
+        *reinterpret_cast<f32x4*>(red + pg * A + a4) = acc;
+        __syncthreads();
+        if (tid < A) {
+            float sum = 0.f;
+            const int used = st.nparts < ng ? st.nparts : ng;
+            for (int h2 = 0; h2 < used; ++h2) sum += red[h2 * A + tid];
+            sum += st.gmm_b1[tid];
+            if (st.q_out) st.q_out[(long)b * st.ldq_out + tid] = sum;      // pre-activation, saved for backward
+            hid[tid] = tanhf(sum);
+        }
+    }
+    __syncthreads();
+    // ---- second layer: 3K rows, one wave each
+    for (int i = wave; i < 3 * kGmmK; i += NT / 64) {
+        float sum = 0.f;
+        for (int a = lane; a < A; a += 64) sum += st.gmm_w2[(long)i * A + a] * hid[a];
+        sum = wave_sum(sum);
+        if (lane == 0) ip[i] = sum + st.gmm_b2[i];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const GmmPar p = gmm_params(ip);
+#pragma unroll
+        for (int k = 0; k < kGmmK; ++k) {
+            const float mu = (st.mu_prev ? st.mu_prev[(long)b * kGmmPad + k] : 0.f) + p.delta[k];
+            st.mu_out[(long)b * kGmmPad + k] = mu;
+            par[k] = p.omega[k] / p.Z[k]; par[8 + k] = mu; par[16 + k] = p.sigma[k] * p.sigma[k];
+        }
+    }
+    __syncthreads();
+    // ---- mixture, mask, softmax
+    const int len = st.lengths ? st.lengths[b] : Tin;
+    float mx = -INFINITY;
+    for (int j = tid; j < Tin; j += NT) {
+        float phi = 0.f;
+#pragma unroll
+        for (int k = 0; k < kGmmK; ++k) {
+            const float dj = (float)j - par[8 + k];
+            phi += par[k] * expf(-(dj * dj) / par[16 + k] / 2.0f);
+        }
+        if (j >= len) phi = d.mask_value;
+        e[j] = phi;
+        mx = fmaxf(mx, phi);
+    }
+    mx = block_reduce(mx, red, true);
+    float sum = 0.f;
+    for (int j = tid; j < Tin; j += NT) { const float x = expf(e[j] - mx); e[j] = x; sum += x; }
+    sum = block_reduce(sum, red, false);
+    const float inv = 1.0f / sum;
+    for (int j = tid; j < Tin; j += NT) {
+        const float w = e[j] * inv;
+        an[j] = w;
+        st.a_out[(long)b * st.lda_out + j] = w;
+    }
+    __syncthreads();
+    // ---- context
+    {
+        const int h = tid / nd, dd = (tid % nd) * 4;
+        if (h < nh) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* mp = st.memory + (long)b * Tin * E + dd;
+#pragma unroll 8
+            for (int j = h; j < Tin; j += nh) acc += an[j] * *reinterpret_cast<const f32x4*>(mp + (long)j * E);
+            *reinterpret_cast<f32x4*>(cred + h * E + dd) = acc;
+        }
+        __syncthreads();
+        for (int c = tid; c < E; c += NT) {
+            float s2 = 0.f;
+            for (int h2 = 0; h2 < nh; ++h2) s2 += cred[h2 * E + c];
+            st.ctx1[(long)b * st.ldctx1 + c] = s2;
+            if (st.ctx2) st.ctx2[(long)b * st.ldctx2 + c] = s2;
+            if (st.ctx16) st.ctx16[(long)b * st.ldctx16 + c] = (__bf16)s2;
+            if (st.ctx16b) st.ctx16b[(long)b * st.ldctx16b + c] = (__bf16)s2;
+        }
+    }
+}
+
+// Backward of one GMM attention step (reverse time), one workgroup per (b, stream).
+//   g_j = dctx . memory_j + dalign_j ; dphi_j = w_j (g_j - sum w g)                            softmax
+//   E_jk = exp(-(j-mu_k)^2 / (2 s_k^2)) ; t_jk = omega_k / Z_k E_jk
+//   domega_k = sum_j dphi_j E_jk / Z_k ; dmu_k = sum_j dphi_j t_jk (j-mu_k)/s_k^2 (+ carry: mu_{t+1} = mu_t + delta_{t+1})
+//   dsigma_k = sum_j dphi_j t_jk ((j-mu_k)^2 / s_k^3 - 1/s_k) ; ddelta_k = dmu_k (total)
+//   through softplus / softmax to the 3K pre-activations, then the second MLP layer (per-item accumulators of dW2, db2)
+//   and tanh: dq_a = (W2^T dip)_a (1 - hid_a^2)  -> the existing dq path (d h via W1, dW1 by the big GEMM, db1 = colsum)
+__global__ __launch_bounds__(NTB) void attention_gmm_step_bwd_kernel(AttnBwdDesc d) {
+    const AttnBwdStream& st = d.st[blockIdx.y];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int Tin = st.Tin, A = d.A, E = d.E;
+    const int Tp = (Tin + 3) & ~3;
+    constexpr int NWV = NTB / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dctx = smem;              // [E]
+    float* hid = dctx + E;           // [A]
+    float* g = hid + A;              // [Tp]
+    float* wS = g + Tp;              // [Tp]
+    float* ip = wS + Tp;             // [16]
+    float* dip = ip + 16;            // [16]
+    float* red2 = dip + 16;          // [NWV + 8]
+    float* psum = red2 + NWV + 8;    // [NWV][16]
+
+    for (int c = tid; c < E; c += NTB) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) if (st.dctx[i]) v += st.dctx[i][(long)b * st.lddctx[i] + c];
+        if (st.part && !d.first) {
+            const float* p = st.part + (long)b * st.ldpart + st.part_col + c;
+            float pv[8];
+#pragma unroll
+            for (int z = 0; z < 8; ++z) pv[z] = z < st.nparts ? p[(long)z * st.part_stride] : 0.f;
+            float acc = 0.f;
+#pragma unroll
+            for (int z = 0; z < 8; ++z) acc += pv[z];
+            v += acc;
+        }
+        dctx[c] = v;
+        st.dctx_out[(long)b * st.lddctx_out + c] = v;
+    }
+    for (int a = tid; a < A; a += NTB) hid[a] = tanhf(st.q[(long)b * st.ldq + a]);
+    for (int j = tid; j < Tin; j += NTB) wS[j] = st.w[(long)b * st.ldw + j];
+    __syncthreads();
+    for (int i = wave; i < 3 * kGmmK; i += NWV) {           // recompute the 3K pre-activations
+        float sum = 0.f;
+        for (int a = lane; a < A; a += 64) sum += st.gmm_w2[(long)i * A + a] * hid[a];
+        sum = wave_sum(sum);
+        if (lane == 0) ip[i] = sum + st.gmm_b2[i];
+    }
+    // g_j: one wave per position, 4 in flight
+    {
+        constexpr int U = 4;
+        for (int j0 = wave; j0 < Tin; j0 += NWV * U) {
+            float sum[U] = {0.f, 0.f, 0.f, 0.f};
+            for (int c = lane * 4; c < E; c += 256) {
+                const f32x4 dc = *reinterpret_cast<const f32x4*>(dctx + c);
+                f32x4 mv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) mv[u] = *reinterpret_cast<const f32x4*>(st.memory + ((long)b * Tin + min(j0 + u * NWV, Tin - 1)) * E + c);
+#pragma unroll
+                for (int u = 0; u < U; ++u) sum[u] += mv[u][0] * dc[0] + mv[u][1] * dc[1] + mv[u][2] * dc[2] + mv[u][3] * dc[3];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u * NWV;
+                const float tot = wave_sum(sum[u]);
+                if (lane == 0 && j < Tin) g[j] = tot + (st.dalign ? st.dalign[(long)b * st.lddalign + j] : 0.f);
+            }
+        }
+    }
+    __syncthreads();
+    // softmax backward: sdot = sum_j w_j g_j
+    float part = 0.f;
+    for (int j = tid; j < Tin; j += NTB) part += wS[j] * g[j];
+    part = wave_sum(part);
+    if (lane == 0) red2[wave] = part;
+    __syncthreads();
+    float sdot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) sdot += red2[i];
+    const GmmPar p = gmm_params(ip);
+    float mu[kGmmK];
+#pragma unroll
+    for (int k = 0; k < kGmmK; ++k) mu[k] = st.mu[(long)b * st.ldmu + k];
+    float s1[kGmmK], s2[kGmmK], s3[kGmmK];
+#pragma unroll
+    for (int k = 0; k < kGmmK; ++k) { s1[k] = 0.f; s2[k] = 0.f; s3[k] = 0.f; }
+    for (int j = tid; j < Tin; j += NTB) {
+        const float dphi = wS[j] * (g[j] - sdot);
+#pragma unroll
+        for (int k = 0; k < kGmmK; ++k) {
+            const float dj = (float)j - mu[k], sg = p.sigma[k], sg2 = sg * sg;
+            const float Ejk = expf(-(dj * dj) / sg2 / 2.0f);
+            const float t = dphi * p.omega[k] / p.Z[k] * Ejk;
+            s1[k] += dphi * Ejk;
+            s2[k] += t * dj / sg2;
+            s3[k] += t * (dj * dj / (sg2 * sg) - 1.0f / sg);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kGmmK; ++k) {
+        const float a1 = wave_sum(s1[k]), a2 = wave_sum(s2[k]), a3 = wave_sum(s3[k]);
+        if (lane == 0) { psum[wave * 16 + k] = a1; psum[wave * 16 + 5 + k] = a2; psum[wave * 16 + 10 + k] = a3; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float S[15];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) { float v = 0.f; for (int w2 = 0; w2 < NWV; ++w2) v += psum[w2 * 16 + i]; S[i] = v; }
+        float dom[kGmmK], wsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < kGmmK; ++k) { dom[k] = S[k] / p.Z[k]; wsum += p.omega[k] * dom[k]; }
+#pragma unroll
+        for (int k = 0; k < kGmmK; ++k) {
+            float dmu = S[5 + k];
+            float* cp = st.mu_carry + (long)b * kGmmPad + k;
+            if (!d.first) dmu += *cp;
+            *cp = dmu;                                                   // gradient on mu_{t-1}
+            const float sig_d = 1.0f / (1.0f + expf(-ip[kGmmK + k])), sig_s = 1.0f / (1.0f + expf(-ip[2 * kGmmK + k]));
+            dip[k] = p.omega[k] * (dom[k] - wsum);                       // softmax
+            dip[kGmmK + k] = dmu * (ip[kGmmK + k] > 20.f ? 1.0f : sig_d);            // softplus'
+            dip[2 * kGmmK + k] = S[10 + k] * (ip[2 * kGmmK + k] > 20.f ? 1.0f : sig_s);
+        }
+        float* db = st.db2_acc + (long)b * 16;
+#pragma unroll
+        for (int i = 0; i < 15; ++i) db[i] = (d.first ? 0.f : db[i]) + dip[i];
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * kGmmK * A; i += NTB) {                     // dW2[i][a] += dip_i hid_a
+        float* pw = st.dw2_acc + (long)b * 3 * kGmmK * A + i;
+        *pw = (d.first ? 0.f : *pw) + dip[i / A] * hid[i % A];
+    }
+    for (int a = tid; a < A; a += NTB) {
+        float dh = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3 * kGmmK; ++i) dh += st.gmm_w2[(long)i * A + a] * dip[i];
+        st.dq_out[(long)b * st.lddq_out + a] = dh * (1.0f - hid[a] * hid[a]);
+    }
+}
+
 }  // namespace
 
 size_t attention_fwd_smem(const AttnStepDesc& d, bool with_pa) {
@@ -1090,6 +1362,23 @@ size_t attention_fwd_smem(const AttnStepDesc& d, bool with_pa) {
 
 int attention_step_fwd(const AttnStepDesc& din, hipStream_t s) {
     AttnStepDesc d = din;
+    if (d.kind == 2) {                                               // GMM
+        T2_REQUIRE(d.nstreams >= 1 && d.nstreams <= 2 && d.A % 4 == 0 && d.A <= 256 && NT % (d.A / 4) == 0 && d.E % 4 == 0 && NT % (d.E / 4) == 0,
+                   "attention_step (GMM): A=%d E=%d unsupported", d.A, d.E);
+        int Tmax = 0;
+        for (int i = 0; i < d.nstreams; ++i) {
+            Tmax = d.st[i].Tin > Tmax ? d.st[i].Tin : Tmax;
+            T2_REQUIRE(d.st[i].qpart && d.st[i].gmm_b1 && d.st[i].gmm_w2 && d.st[i].gmm_b2 && d.st[i].mu_out, "attention_step (GMM): missing buffers");
+        }
+        const int Tp = (Tmax + 3) & ~3;
+        const size_t smem = ((size_t)d.A + 2 * Tp + 4 * NT + (size_t)(NT / (d.E / 4)) * d.E + 16 + 32) * sizeof(float);
+        T2_REQUIRE(smem <= 160 * 1024, "attention_step (GMM): T_in too long for LDS (%zu bytes)", smem);
+        if (smem > 64 * 1024)
+            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_gmm_step_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(attention_gmm_step_fwd_kernel, dim3(d.B, d.nstreams), dim3(NT), smem, s, d);
+        T2_LAUNCH_CHECK();
+        return 0;
+    }
     T2_REQUIRE(d.nstreams >= 1 && d.nstreams <= 2, "attention_step: nstreams=%d", d.nstreams);
     T2_REQUIRE(d.A % 4 == 0 && d.A <= 256 && NT % (d.A / 4) == 0, "attention_step: attention_dim %d must be a multiple of 4 dividing %d, <= 256", d.A, 4 * NT);
     T2_REQUIRE(d.E % 4 == 0 && d.E / 4 <= NT && NT % (d.E / 4) == 0, "attention_step: encoder dim %d unsupported", d.E);
@@ -1124,6 +1413,19 @@ int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s) {
     T2_REQUIRE(d.A % 4 == 0 && d.A <= 256 && d.E % 4 == 0, "attention_bwd: A=%d E=%d unsupported", d.A, d.E);
     int Tmax = 0;
     for (int i = 0; i < d.nstreams; ++i) Tmax = d.st[i].Tin > Tmax ? d.st[i].Tin : Tmax;
+    if (d.kind == 2) {                                               // GMM
+        for (int i = 0; i < d.nstreams; ++i)
+            T2_REQUIRE(d.st[i].w && d.st[i].gmm_w2 && d.st[i].gmm_b2 && d.st[i].mu && d.st[i].mu_carry && d.st[i].dw2_acc && d.st[i].db2_acc,
+                       "attention_bwd (GMM): missing buffers");
+        const int Tp = (Tmax + 3) & ~3;
+        const size_t smem = ((size_t)d.E + d.A + 2 * Tp + 32 + NTB / 64 + 8 + (NTB / 64) * 16) * sizeof(float);
+        T2_REQUIRE(smem <= 160 * 1024, "attention_bwd (GMM): T_in too long for LDS (%zu bytes)", smem);
+        if (smem > 64 * 1024)
+            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_gmm_step_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(attention_gmm_step_bwd_kernel, dim3(d.B, d.nstreams), dim3(NTB), smem, s, d);
+        T2_LAUNCH_CHECK();
+        return 0;
+    }
     if (d.kind == 1) {
         T2_REQUIRE(d.Kc % 2 == 1 && d.F >= 1 && d.F <= 32, "attention_bwd (LSA): location layer F=%d (<= 32) Kc=%d (odd) unsupported", d.F, d.Kc);
         for (int i = 0; i < d.nstreams; ++i)

@@ -113,7 +113,7 @@ int check_dims(const t2_dims& d) {
     T2_REQUIRE(d.prenet_dim % 64 == 0 && d.enc_dim % 64 == 0 && d.att_rnn_dim % 64 == 0 && d.dec_rnn_dim % 64 == 0,
                "prenet/encoder/rnn dims must be multiples of 64 (got %d %d %d %d)", d.prenet_dim, d.enc_dim, d.att_rnn_dim, d.dec_rnn_dim);
     T2_REQUIRE(d.att_dim % 4 == 0 && d.att_dim <= 256, "attention_dim %d unsupported", d.att_dim);
-    T2_REQUIRE(d.attention_kind == T2_ATTN_SMA || d.attention_kind == T2_ATTN_LSA || d.attention_kind == T2_ATTN_FWD2, "unknown attention kind %d", d.attention_kind);
+    T2_REQUIRE(d.attention_kind == T2_ATTN_SMA || d.attention_kind == T2_ATTN_LSA || d.attention_kind == T2_ATTN_FWD2 || d.attention_kind == T2_ATTN_GMM, "unknown attention kind %d", d.attention_kind);
     return 0;
 }
 
@@ -161,7 +161,7 @@ void layout_of(const t2_dims& d, const Sizes& z, t2_decoder_layout* L) {
     L->cna = take(BT * z.Ha); L->cnas = take(BT * z.Ha); L->ca = take(BT * z.Ha); L->cas = take(BT * z.Ha);
     L->din = take(BT * z.WD);
     L->psel = take(BT * z.Tin); L->psels = take(BT * z.Tsub);
-    L->wcum = take(BT * z.Tin); L->wcums = take(BT * z.Tsub);
+    L->wcum = take(BT * std::max(z.Tin, kGmmPad)); L->wcums = take(BT * std::max(z.Tsub, kGmmPad));   // LSA cumulative weights / GMM means
     L->pred = take(BT * 4 * z.Hd); L->gd = take(BT * 4 * z.Hd);
     L->cnd = take(BT * z.Hd); L->cd = take(BT * z.Hd);
     L->dout = take(BT * z.WO);
@@ -316,7 +316,11 @@ int attention_step(const Dec& c, int t) {
         st.lengths = s ? c.len_sub : c.len;
         st.a_prev = t > 0 ? al + (long)(t - 1) * Tin : nullptr; st.lda_prev = ldA;
         st.a_out = al + (long)t * Tin; st.lda_out = ldA;
-        if (d.kind == T2_ATTN_SMA) {
+        if (d.kind == T2_ATTN_GMM) {
+            float* mu = c.P(s ? L.wcums : L.wcum);                    // [T,B,kGmmPad]
+            st.mu_prev = t > 0 ? mu + c.R(t - 1) * kGmmPad : nullptr; st.mu_out = mu + c.R(t) * kGmmPad;
+            st.gmm_b1 = aw.mlp_b1; st.gmm_w2 = aw.mlp_w2; st.gmm_b2 = aw.mlp_b2;
+        } else if (d.kind == T2_ATTN_SMA) {
             st.p_out = c.P(s ? L.psels : L.psel) + (long)t * Tin; st.ldp_out = ldA;
         } else {
             float* wc = c.P(s ? L.wcums : L.wcum);
@@ -333,6 +337,7 @@ int attention_step(const Dec& c, int t) {
         st.site_noise = s ? T2_SITE_NOISE_SUB : T2_SITE_NOISE;
         st.idx_base = (uint32_t)(c.R(t) * Tin); st.idx_bstride = (uint32_t)Tin;          // logical [T,B,Tin]
     }
+    if (d.kind == T2_ATTN_GMM) d.kind = 2;                       // kernel-level kind (0 SMA, 1 LSA, 2 GMM)
     ProfScope ps(PK_ATTN_FWD, c.s);
     return attention_step_fwd(d, c.s);
 }
@@ -392,6 +397,7 @@ int projection(const Dec& c, const float* X, long ldx, int M, float* mel, long l
 
 int processed_memory(const Dec& c) {
     const Sizes& z = c.z;
+    if (c.d.attention_kind == T2_ATTN_GMM) return 0;               // purely location-based: memory_layer is never used
     GemmDesc g = linear(c.memory, z.E, c.w.attn.wm, z.E, c.P(c.L.pm), z.A, z.B * z.Tin, z.A, z.E);
     T2_TRY(gemm(g, c.s));
     if (z.NS == 1) return 0;
@@ -425,8 +431,10 @@ void bwd_layout_of(const t2_dims& d, const Sizes& z, t2_decoder_bwd_layout* L) {
     L->dpm = take((size_t)z.B * z.Tin * z.A); L->dpms = take((size_t)z.B * z.Tsub * z.A);
     L->carry = take((size_t)2 * z.B * z.Tin); L->carrys = take((size_t)2 * z.B * z.Tsub);   // ping-pong by step parity
     const bool lsa = d.attention_kind == T2_ATTN_LSA;          // LSA: cumulative-weight carry + per-item location-layer gradients
-    const size_t ncv = lsa ? (size_t)z.B * d.loc_filters * 2 * d.loc_kernel : 0, nds = lsa ? (size_t)z.B * z.A * d.loc_filters : 0;
-    L->carryc = take(lsa ? (size_t)z.B * z.Tin : 0); L->carrycs = take(lsa ? (size_t)z.B * z.Tsub : 0);
+    const bool gmm = d.attention_kind == T2_ATTN_GMM;          // GMM: mean carry [B,8] + per-item db2 [B,16] / dW2 [B,3K*A]
+    const size_t ncv = lsa ? (size_t)z.B * d.loc_filters * 2 * d.loc_kernel : gmm ? (size_t)z.B * 16 : 0;
+    const size_t nds = lsa ? (size_t)z.B * z.A * d.loc_filters : gmm ? (size_t)z.B * 3 * kGmmK * z.A : 0;
+    L->carryc = take(lsa ? (size_t)z.B * z.Tin : gmm ? (size_t)z.B * kGmmPad : 0); L->carrycs = take(lsa ? (size_t)z.B * z.Tsub : gmm ? (size_t)z.B * kGmmPad : 0);
     L->dlconv = take(ncv); L->dlconvs = take(ncv); L->dldense = take(nds); L->dldenses = take(nds);
     L->dcd = take((size_t)z.B * z.Hd); L->dca = take((size_t)z.B * z.Ha); L->dcas = take((size_t)z.B * z.Ha);
     L->partd = take((size_t)ksd * z.B * z.Hd);
@@ -529,7 +537,14 @@ int att_bwd_step(const Bwd& c, int t) {
         if (t > 0) { st.a_prev = al + (long)(t - 1) * Tin; st.lda_prev = ldA; }
         const t2_attention_weights& aw = s ? c.w.attn_sub : c.w.attn;
         st.v = aw.v;
-        if (ab.kind == T2_ATTN_SMA) {
+        if (ab.kind == T2_ATTN_GMM) {
+            st.w = al + (long)t * Tin; st.ldw = ldA;
+            st.gmm_w2 = aw.mlp_w2; st.gmm_b2 = aw.mlp_b2;
+            st.mu = c.W(s ? c.L.wcums : c.L.wcum) + c.R(t) * kGmmPad; st.ldmu = kGmmPad;
+            st.mu_carry = c.S(s ? c.BL.carrycs : c.BL.carryc);
+            st.db2_acc = c.S(s ? c.BL.dlconvs : c.BL.dlconv);
+            st.dw2_acc = c.S(s ? c.BL.dldenses : c.BL.dldense);
+        } else if (ab.kind == T2_ATTN_SMA) {
             st.p = c.W(s ? c.L.psels : c.L.psel) + (long)t * Tin; st.ldp = ldA;
         } else {
             st.w = al + (long)t * Tin; st.ldw = ldA;
@@ -547,6 +562,7 @@ int att_bwd_step(const Bwd& c, int t) {
         st.dv_acc = c.S(s ? c.BL.dvs : c.BL.dv);
         st.dpm_acc = c.S(s ? c.BL.dpms : c.BL.dpm);
     }
+    if (ab.kind == T2_ATTN_GMM) ab.kind = 2;                     // kernel-level kind
     { ProfScope ps(PK_ATTN_BWD, c.s); T2_TRY(attention_step_bwd(ab, c.s)); }
     // 2. LSTM pointwise backward
     LstmBwdPointDesc p{};
@@ -788,7 +804,19 @@ int t2_decoder_backward(const t2_dims* dims_in, const t2_decoder_weights* w, con
         float* DQ = c.S(s ? BL.dqs : BL.dq);
         if (nsp == 2) T2_TRY(fold_halves(DQ, BT, z.A, c.s));               // dq row = partial 0 + partial 1
         T2_TRY(gemm(matmul_tn(c, DQ, 2 * z.A, DIN + hoff, z.WD, ag.wq, z.Ha, z.A, z.Ha, BT), c.s));
-        T2_TRY(batch_sum(c.S(s ? BL.dvs : BL.dv), nsp * z.B, z.A, ag.v, c.s));
+        const bool gmm = dims->attention_kind == T2_ATTN_GMM;
+        if (gmm) {
+            // mlp.0.weight was handled as the query projection above; mlp.0.bias = column sums of dq; second layer from
+            // the per-item accumulators; memory_layer takes no part in the arithmetic (its gradient is None in the reference)
+            T2_REQUIRE(ag.mlp_b1 && ag.mlp_w2 && ag.mlp_b2, "t2_decoder_backward: GMM needs mlp_b1 / mlp_w2 / mlp_b2 gradient buffers");
+            T2_TRY(colsum(DQ, 2 * z.A, BT, z.A, ag.mlp_b1, nullptr, cws, c.s));
+            T2_TRY(batch_sum(c.S(s ? BL.dldenses : BL.dldense), z.B, 3 * kGmmK * z.A, ag.mlp_w2, c.s));
+            float* b2tmp = cws;                                          // 16 floats of scratch (slot 15 is padding)
+            T2_TRY(batch_sum(c.S(s ? BL.dlconvs : BL.dlconv), z.B, 16, b2tmp, c.s));
+            T2_CHECK_HIP(hipMemcpyAsync(ag.mlp_b2, b2tmp, 3 * kGmmK * sizeof(float), hipMemcpyDeviceToDevice, c.s));
+        } else {
+            T2_TRY(batch_sum(c.S(s ? BL.dvs : BL.dv), nsp * z.B, z.A, ag.v, c.s));
+        }
         if (dims->attention_kind == T2_ATTN_LSA) {
             T2_REQUIRE(ag.loc_conv && ag.loc_dense, "t2_decoder_backward: LSA needs loc_conv / loc_dense gradient buffers");
             T2_TRY(batch_sum(c.S(s ? BL.dlconvs : BL.dlconv), z.B, dims->loc_filters * 2 * dims->loc_kernel, ag.loc_conv, c.s));
@@ -796,15 +824,17 @@ int t2_decoder_backward(const t2_dims* dims_in, const t2_decoder_weights* w, con
         }
         const float* mem = s ? a->memory_sub : a->memory;
         float* dmem = s ? a->d_memory_sub : a->d_memory;
-        const float* DPM = c.S(s ? BL.dpms : BL.dpm);
-        T2_TRY(gemm(matmul_tn(c, DPM, z.A, mem, z.E, ag.wm, z.E, z.A, z.E, z.B * Tin), c.s));
-        // d(memory) = dPM . Wm  +  per item: align^T [Tin x T] . dctx [T x E]
-        T2_TRY(gemm(matmul_nn(DPM, z.A, aw.wm, z.E, dmem, z.E, z.B * Tin, z.E, z.A), c.s));
+        if (!gmm) {
+            const float* DPM = c.S(s ? BL.dpms : BL.dpm);
+            T2_TRY(gemm(matmul_tn(c, DPM, z.A, mem, z.E, ag.wm, z.E, z.A, z.E, z.B * Tin), c.s));
+            // d(memory) = dPM . Wm  +  per item: align^T [Tin x T] . dctx [T x E]
+            T2_TRY(gemm(matmul_nn(DPM, z.A, aw.wm, z.E, dmem, z.E, z.B * Tin, z.E, z.A), c.s));
+        }
         GemmDesc dm = gemm_desc();
         dm.A = s ? a->align_sub : a->align; dm.sam = 1; dm.sak = Tin; dm.bsA = (long)z.T * Tin;
         dm.B = c.S(s ? BL.dctxs : BL.dctx); dm.sbk = (long)z.B * z.E; dm.sbn = 1; dm.bsB = z.E;     // dctx is [T,B,E]
         dm.C = dmem; dm.ldc = z.E; dm.bsC = (long)Tin * z.E;
-        dm.M = Tin; dm.N = z.E; dm.K = z.T; dm.batch = z.B; dm.beta = 1.f;
+        dm.M = Tin; dm.N = z.E; dm.K = z.T; dm.batch = z.B; dm.beta = gmm ? 0.f : 1.f;
         T2_TRY(gemm(dm, c.s));
     }
     return 0;

@@ -116,10 +116,14 @@ struct AttnStream {
     const float* loc_conv; const float* loc_dense;   // LSA: [F,2,Kc], [A,F]
     uint32_t site_noise; uint32_t idx_base, idx_bstride;   // SMA noise index = idx_base + b*idx_bstride + j
     int Tin;
+    // GMM attention (kind 2): wq / qpart carry mlp.0 (Linear Ha->A); second layer and state below
+    const float* gmm_b1; const float* gmm_w2; const float* gmm_b2;   // [A], [3K, A], [3K]
+    const float* mu_prev; float* mu_out;  // [B, kGmmPad] mixture means before / after this step (mu_prev null at t=0 -> 0)
 };
+constexpr int kGmmK = 5, kGmmPad = 8;     // mixtures (attention.py:409), row pitch of the mean buffers
 struct AttnStepDesc {
     AttnStream st[2]; int nstreams; int B, A, E; int kind;   // kind 0 = SMA, 1 = LSA
-    int F, Kc; float noise_std; uint64_t seed; float mask_value; int first;
+    int F, Kc; float noise_std; uint64_t seed; float mask_value; int first;   // kind 2 = GMM (attention_gmm_step_fwd)
     int lsa_pa;                                               // set by the launcher (MFMA path of the LSA dense projection)
     int max_pos;                                              // > 0: valid length clamped to max_pos (ForwardAttentionV2, see c_api.hip)
 };
@@ -148,6 +152,11 @@ struct AttnBwdStream {
     const float* loc_conv; const float* loc_dense;   // [F,2,Kc], [A,F]
     float* carry_cum;                      // [B,Tin] gradient on the cumulative weights (in/out); `carry` holds the w_{t-1} part
     float* dconv_acc; float* ddense_acc;   // [B,F*2*Kc], [B,A*F] per-item weight gradients accumulated over steps
+    // GMM only (kind 2): q = saved pre-activation of mlp.0 (incl. bias); w = saved weights of step t
+    const float* gmm_w2; const float* gmm_b2;
+    const float* mu; long ldmu;            // [B, kGmmPad] mixture means of step t
+    float* mu_carry;                       // [B, kGmmPad] gradient on the means flowing in from step t+1 (in/out)
+    float* dw2_acc; float* db2_acc;        // [B, 3K*A], [B, 16] per-item accumulators
 };
 struct AttnBwdDesc { AttnBwdStream st[2]; int nstreams; int B, A, E; int first; int kind, F, Kc; int nsplit; };   // nsplit: SMA only
 int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s);

@@ -20,7 +20,7 @@ from torch import nn
 from . import _lib as L
 from . import blocks
 from . import ops
-from .attention import ForwardAttentionV2, LocationSensitiveAttention, StepwiseMonotonicAttention
+from .attention import ForwardAttentionV2, GMMAttention, LocationSensitiveAttention, StepwiseMonotonicAttention
 from .layers import ConvNorm, LinearNorm
 from .utils import get_mask_from_lengths, to_gpu
 
@@ -168,11 +168,12 @@ class Decoder(nn.Module):
         # The reference builds attention_layer_bert only for SMA and then uses it unconditionally
         # (model.py:158-191 vs :261,356); here both streams always get their module.
         att_cls = {"StepwiseMonotonicAttention": StepwiseMonotonicAttention, "ForwardAttentionV2": ForwardAttentionV2,
+                   "GMMAttention": GMMAttention,
                    "LSA": LocationSensitiveAttention, "LocationSensitiveAttention": LocationSensitiveAttention}.get(hp.attention)
         if att_cls is None:
-            raise NotImplementedError(f"attention '{hp.attention}' is not built yet (SURVEY.md §8f N1: GMMAttention, "
-                                      "DynamicConvolutionAttention); use StepwiseMonotonicAttention, LSA or ForwardAttentionV2")
-        print({"SMA": "Use SMA", "LSA": "Use LSA", "FWD2": "Use ForwardAttention"}[att_cls.kind])      # model.py:159-191
+            raise NotImplementedError(f"attention '{hp.attention}' is not built yet (SURVEY.md §8f N1: "
+                                      "DynamicConvolutionAttention); use StepwiseMonotonicAttention, LSA, ForwardAttentionV2 or GMMAttention")
+        print({"SMA": "Use SMA", "LSA": "Use LSA", "FWD2": "Use ForwardAttention", "GMM": "Use GMMA"}[att_cls.kind])      # model.py:159-191
         args = (Ha, E, hp.attention_dim, hp.attention_location_n_filters, hp.attention_location_kernel_size)
         self.attention_layer = att_cls(*args)
         if not single:

@@ -98,7 +98,8 @@ def build_reference(ref_model, ref_attention, ref_hparams, attention, seed=1234)
     if attention != "StepwiseMonotonicAttention":
         # model.py:158-191 builds attention_layer_bert only for SMA and then uses it unconditionally (:261,356): the
         # harness supplies the missing module of the same class
-        cls = ref_attention.ForwardAttentionV2 if attention == "ForwardAttentionV2" else ref_attention.LocationSensitiveAttention
+        cls = {"ForwardAttentionV2": ref_attention.ForwardAttentionV2, "GMMAttention": ref_attention.GMMAttention}.get(
+            attention, ref_attention.LocationSensitiveAttention)
         m.decoder.attention_layer_bert = cls(
             hps.attention_rnn_dim, hps.encoder_embedding_dim, hps.attention_dim,
             hps.attention_location_n_filters, hps.attention_location_kernel_size)
@@ -257,6 +258,7 @@ def main():
     gen_inference(refs, SMA, "sma_infer", 21, 11)
     gen_inference(refs, LSA, "lsa_infer", 21, 11)
     gen_fa2(refs)
+    gen_gmm(refs)
 
 
 def gen_fa2(refs):
@@ -266,8 +268,19 @@ def gen_fa2(refs):
     gen_forward(refs, FA2, "fa2_small_train", 3, 13, 8, 12, training=True, with_grads=True)
 
 
+def gen_gmm(refs):
+    """GMMAttention; `python make_golden.py gmm` writes only these."""
+    GMM = "GMMAttention"
+    gen_forward(refs, GMM, "gmm_small_eval", 2, 13, 8, 12, training=False)
+    gen_forward(refs, GMM, "gmm_small_train", 3, 13, 8, 12, training=True, with_grads=True)
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["fa2"]:
+    if sys.argv[1:] == ["gmm"]:
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        gen_gmm(import_reference())
+    elif sys.argv[1:] == ["fa2"]:
         torch.manual_seed(0)
         torch.set_num_threads(8)
         gen_fa2(import_reference())

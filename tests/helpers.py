@@ -7,7 +7,7 @@ import torch
 from oracle import recipe
 from oracle import tacotron2_oracle as O
 
-SMA, LSA, FA2 = "StepwiseMonotonicAttention", "LSA", "ForwardAttentionV2"
+SMA, LSA, FA2, GMM = "StepwiseMonotonicAttention", "LSA", "ForwardAttentionV2", "GMMAttention"
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
