@@ -26,6 +26,7 @@ extern "C" {
 
 #define T2_ATTN_SMA 0 /* StepwiseMonotonicAttention, attention.py:291-398 (hparams default) */
 #define T2_ATTN_LSA 1 /* LocationSensitiveAttention, attention.py:25-85 */
+#define T2_ATTN_DCA 4  /* DynamicConvolutionAttention (attention.py:195-289) */
 #define T2_ATTN_GMM 3  /* GMMAttention version '2', K = 5 (attention.py:401-506) */
 #define T2_ATTN_FWD2 2 /* ForwardAttentionV2 as model.py drives it (attention.py:87-151 with the never-updated log_alpha of
                           model.py:266-270,355): LSA energies, softmax over the first two positions; LSA weight layout */
@@ -79,6 +80,11 @@ typedef struct t2_attention_weights {
     const float* mlp_b1;    /* mlp.0.bias   [A] */
     const float* mlp_w2;    /* mlp.2.weight [15, A] */
     const float* mlp_b2;    /* mlp.2.bias   [15] */
+    /* DynamicConvolutionAttention (T2_ATTN_DCA): wq = W.weight [A, att_rnn], mlp_b1 = W.bias [A], mlp_w2 = V.weight [168, A],
+     * loc_conv = F.weight [8,1,21], loc_dense = U.weight [A,8], v = v.weight [1,A]; memory_layer is not used */
+    const float* dca_T;     /* T.weight [A, 8] */
+    const float* dca_bT;    /* T.bias   [A] */
+    const float* dca_P;     /* P buffer [11] (prior taps; no gradient) */
 } t2_attention_weights;
 typedef struct t2_lstm_weights { const float *w_ih, *w_hh, *b_ih, *b_hh; } t2_lstm_weights;
 typedef struct t2_decoder_weights {
@@ -142,7 +148,7 @@ int t2_decoder_forward(const t2_dims* dims, const t2_decoder_weights* w, const t
  * weights; d_memory / d_memory_sub receive the gradient wrt the encoder memories.
  * Both attention kinds; for LSA the location-layer gradient pointers of t2_attention_grads must be set. */
 typedef struct t2_lstm_grads { float *w_ih, *w_hh, *b_ih, *b_hh; } t2_lstm_grads;
-typedef struct t2_attention_grads { float *wq, *wm, *v, *loc_conv, *loc_dense, *mlp_b1, *mlp_w2, *mlp_b2; } t2_attention_grads;
+typedef struct t2_attention_grads { float *wq, *wm, *v, *loc_conv, *loc_dense, *mlp_b1, *mlp_w2, *mlp_b2, *dca_T, *dca_bT, *dca_P; } t2_attention_grads;
 typedef struct t2_decoder_grads {
     float *prenet_w1, *prenet_w2, *prenet_sub_w1, *prenet_sub_w2;
     t2_lstm_grads att, att_sub;

@@ -57,6 +57,15 @@ def state_dict_spec(hp: dict) -> List[Tuple[str, Tuple[int, ...], str]]:
             add(prefix + ".memory_layer.linear_layer.weight", (A, E), "linear")
             add(prefix + ".v.weight", (1, A), "linear")
             add(prefix + ".query_layer.linear_layer.weight", (A, Ha), "linear")
+        elif hp["attention"] == "DynamicConvolutionAttention":      # attention.py:199-230 (the P buffer sits between memory_layer and W)
+            add(prefix + ".P", (11,), "dca_prior")
+            add(prefix + ".memory_layer.linear_layer.weight", (A, E), "linear")
+            add(prefix + ".W.weight", (A, Ha), "linear"); add(prefix + ".W.bias", (A,), "bias")
+            add(prefix + ".V.weight", (168, A), "linear")
+            add(prefix + ".F.weight", (8, 1, 21), "conv")
+            add(prefix + ".U.weight", (A, 8), "linear")
+            add(prefix + ".T.weight", (A, 8), "linear"); add(prefix + ".T.bias", (A,), "bias")
+            add(prefix + ".v.weight", (1, A), "linear")
         elif hp["attention"] == "GMMAttention":                      # attention.py:405-415
             add(prefix + ".memory_layer.linear_layer.weight", (A, E), "linear")
             add(prefix + ".mlp.0.weight", (A, Ha), "linear"); add(prefix + ".mlp.0.bias", (A,), "bias")
@@ -136,6 +145,9 @@ def make_weights(hp: dict, seed: int = 1234, single: bool = False) -> Dict[str, 
         elif kind == "emb":
             bound = math.sqrt(3.0) * math.sqrt(2.0 / (hp["n_symbols"] + hp["symbols_embedding_dim"]))
             a = g.uniform(-bound, bound, size=shape)
+        elif kind == "dca_prior":                     # attention.py:219-221: beta-binomial prior, flipped
+            from scipy.stats import betabinom
+            a = betabinom.pmf(np.arange(shape[0]), shape[0] - 1, 0.1, 0.9)[::-1].copy()
         elif kind == "bias":
             a = g.uniform(-0.05, 0.05, size=shape)
         elif kind == "bn_w":

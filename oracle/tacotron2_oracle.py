@@ -252,7 +252,35 @@ def gmm_step(query, memory, mu_prev, mask, P, prefix):
     return ctx, w, mu
 
 
+def dca_step(query, memory, align_prev, mask, P, prefix):
+    """DynamicConvolutionAttention.forward (attention.py:236-289).  align_prev: [B,Tin] (init_attention: one-hot at 0)."""
+    Kd, Cd = 21, 8
+    prior = P[prefix + ".P"]
+    p = F.conv1d(F.pad(align_prev.unsqueeze(1), (prior.numel() - 1, 0)), prior.view(1, 1, -1))
+    p = torch.log(p.clamp_min(1e-6)).squeeze(1)
+    G = F.linear(torch.tanh(F.linear(query, P[prefix + ".W.weight"], P[prefix + ".W.bias"])), P[prefix + ".V.weight"])
+    g = F.conv1d(align_prev.unsqueeze(0), G.view(-1, 1, Kd), padding=(Kd - 1) // 2, groups=query.size(0))
+    g = g.view(query.size(0), Cd, -1).transpose(1, 2)
+    f = F.conv1d(align_prev.unsqueeze(1), P[prefix + ".F.weight"], padding=(Kd - 1) // 2).transpose(1, 2)
+    e = F.linear(torch.tanh(F.linear(f, P[prefix + ".U.weight"]) + F.linear(g, P[prefix + ".T.weight"], P[prefix + ".T.bias"])),
+                 P[prefix + ".v.weight"]).squeeze(-1) + p
+    if mask is not None:
+        e = e.masked_fill(mask, -float("inf"))
+    w = F.softmax(e, dim=1)
+    ctx = torch.bmm(w.unsqueeze(1), memory).squeeze(1)
+    return ctx, w
+
+
 def _attend(kind, query, memory, pm, w_prev, w_cum, mask, P, prefix, st=None):
+    if kind == "DynamicConvolutionAttention":
+        key = "a_" + prefix
+        a_prev = st.gmm.get(key)
+        if a_prev is None:                                       # attention.py:232-234
+            a_prev = memory.new_zeros(memory.shape[0], memory.shape[1])
+            a_prev[:, 0] = 1.0
+        ctx, w = dca_step(query, memory, a_prev, mask, P, prefix)
+        st.gmm[key] = w
+        return ctx, w
     if kind == "GMMAttention":
         key = "mu_" + prefix
         mu_prev = st.gmm.get(key)

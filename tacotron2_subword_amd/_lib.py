@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libt2amd.so")
 
-ATTN_SMA, ATTN_LSA, ATTN_FWD2, ATTN_GMM = 0, 1, 2, 3
+ATTN_SMA, ATTN_LSA, ATTN_FWD2, ATTN_GMM, ATTN_DCA = 0, 1, 2, 3, 4
 
 SITE = dict(PRENET1=1, PRENET2=2, PRENET1_SUB=3, PRENET2_SUB=4, ATT_H=5, ATT_C=6, ATT_H_SUB=7, ATT_C_SUB=8,
             DEC_H=9, DEC_C=10, NOISE=11, NOISE_SUB=12, ENC0=16, ENCSUB0=20, POSTNET0=24)
@@ -32,7 +32,8 @@ class Dims(C.Structure):
 
 class AttentionWeights(C.Structure):
     _fields_ = [("wq", C.c_void_p), ("wm", C.c_void_p), ("v", C.c_void_p), ("loc_conv", C.c_void_p), ("loc_dense", C.c_void_p),
-                ("mlp_b1", C.c_void_p), ("mlp_w2", C.c_void_p), ("mlp_b2", C.c_void_p)]
+                ("mlp_b1", C.c_void_p), ("mlp_w2", C.c_void_p), ("mlp_b2", C.c_void_p),
+                ("dca_T", C.c_void_p), ("dca_bT", C.c_void_p), ("dca_P", C.c_void_p)]
 
 
 class LstmWeights(C.Structure):
@@ -215,7 +216,8 @@ def stream() -> int:
 
 def dims_from_hparams(hp, n_streams: int = 2) -> Dims:
     g = (lambda k: hp[k]) if isinstance(hp, dict) else (lambda k: getattr(hp, k))
-    kind = {"StepwiseMonotonicAttention": ATTN_SMA, "ForwardAttentionV2": ATTN_FWD2, "GMMAttention": ATTN_GMM}.get(g("attention"), ATTN_LSA)
+    kind = {"StepwiseMonotonicAttention": ATTN_SMA, "ForwardAttentionV2": ATTN_FWD2, "GMMAttention": ATTN_GMM,
+            "DynamicConvolutionAttention": ATTN_DCA}.get(g("attention"), ATTN_LSA)
     return Dims(int(g("n_mel_channels")) * int(g("n_frames_per_step")), int(g("prenet_dim")), int(g("encoder_embedding_dim")),
                 int(g("attention_rnn_dim")), int(g("decoder_rnn_dim")), int(g("attention_dim")),
                 int(g("attention_location_n_filters")), int(g("attention_location_kernel_size")), kind,
@@ -232,6 +234,9 @@ def decoder_weights(P: dict, kind: int, prefix: str = "decoder.", single: bool =
         if kind == ATTN_SMA:
             return AttentionWeights(p(n + ".query_layer.linear_layer.weight"), p(n + ".memory_layer.linear_layer.weight"),
                                     p(n + ".v.weight"), None, None)
+        if kind == ATTN_DCA:       # W plays the part of the query projection (attention.py:222, 244)
+            return AttentionWeights(p(n + ".W.weight"), None, p(n + ".v.weight"), p(n + ".F.weight"), p(n + ".U.weight"),
+                                    p(n + ".W.bias"), p(n + ".V.weight"), None, p(n + ".T.weight"), p(n + ".T.bias"), p(n + ".P"))
         if kind == ATTN_GMM:       # mlp.0 plays the part of the query projection (attention.py:412-415)
             return AttentionWeights(p(n + ".mlp.0.weight"), None, None, None, None,       # memory_layer is never read
                                     p(n + ".mlp.0.bias"), p(n + ".mlp.2.weight"), p(n + ".mlp.2.bias"))
@@ -293,8 +298,25 @@ def _gmm_keys():
 DECODER_PARAM_KEYS_GMM = _gmm_keys()
 
 
+def _dca_keys():
+    """Parameters that receive a gradient with DynamicConvolutionAttention (memory_layer does not; P is a buffer)."""
+    out = []
+    for k in DECODER_PARAM_KEYS_SMA:
+        if ".query_layer." in k:
+            n = k[:k.index(".query_layer.")]
+            out += [n + s for s in (".W.weight", ".W.bias", ".V.weight", ".F.weight", ".U.weight", ".T.weight", ".T.bias", ".v.weight")]
+        elif ".memory_layer." in k or k.endswith(".v.weight"):
+            continue
+        else:
+            out.append(k)
+    return out
+
+
+DECODER_PARAM_KEYS_DCA = _dca_keys()
+
+
 def decoder_param_keys(kind: int, single: bool = False):
-    keys = DECODER_PARAM_KEYS_SMA if kind == ATTN_SMA else DECODER_PARAM_KEYS_GMM if kind == ATTN_GMM else DECODER_PARAM_KEYS_LSA
+    keys = {ATTN_SMA: DECODER_PARAM_KEYS_SMA, ATTN_GMM: DECODER_PARAM_KEYS_GMM, ATTN_DCA: DECODER_PARAM_KEYS_DCA}.get(kind, DECODER_PARAM_KEYS_LSA)
     return [k for k in keys if "_bert" not in k] if single else keys
 
 
@@ -307,6 +329,9 @@ def decoder_grads(G: dict, prefix: str = "decoder.", single: bool = False, kind:
         if kind == ATTN_SMA:
             return AttentionGrads(p(n + ".query_layer.linear_layer.weight"), p(n + ".memory_layer.linear_layer.weight"),
                                   p(n + ".v.weight"), None, None)
+        if kind == ATTN_DCA:
+            return AttentionGrads(p(n + ".W.weight"), None, p(n + ".v.weight"), p(n + ".F.weight"), p(n + ".U.weight"),
+                                  p(n + ".W.bias"), p(n + ".V.weight"), None, p(n + ".T.weight"), p(n + ".T.bias"), None)
         if kind == ATTN_GMM:
             return AttentionGrads(p(n + ".mlp.0.weight"), None, None, None, None,
                                   p(n + ".mlp.0.bias"), p(n + ".mlp.2.weight"), p(n + ".mlp.2.bias"))

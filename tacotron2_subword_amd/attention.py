@@ -60,6 +60,31 @@ class GMMAttention(nn.Module):
                                  nn.Linear(attention_dim, 3 * self.K))
 
 
+class DynamicConvolutionAttention(nn.Module):
+    """attention.py:195-289: 8 static + 8 dynamic 21-tap filters over the previous alignment plus an 11-tap beta-binomial
+    prior (alpha 0.1, beta 0.9).  memory_layer exists but takes no part in the arithmetic; P is a buffer."""
+    kind = "DCA"
+
+    def __init__(self, attention_rnn_dim, embedding_dim, attention_dim, attention_location_n_filters,
+                 attention_location_kernel_size):
+        super().__init__()
+        import numpy as np
+        import torch
+        from scipy.stats import betabinom
+        self.memory_layer = LinearNorm(embedding_dim, attention_dim, bias=False, w_init_gain="tanh")
+        self.score_mask_value = -float("inf")
+        static_channels, static_kernel_size, dynamic_channels, dynamic_kernel_size, prior_length = 8, 21, 8, 21, 11
+        self.prior_length, self.dynamic_channels, self.dynamic_kernel_size = prior_length, dynamic_channels, dynamic_kernel_size
+        prior = betabinom.pmf(np.arange(prior_length), prior_length - 1, 0.1, 0.9)
+        self.register_buffer("P", torch.FloatTensor(prior).flip(0))
+        self.W = nn.Linear(attention_rnn_dim, attention_dim)
+        self.V = nn.Linear(attention_dim, dynamic_channels * dynamic_kernel_size, bias=False)
+        self.F = nn.Conv1d(1, static_channels, static_kernel_size, padding=(static_kernel_size - 1) // 2, bias=False)
+        self.U = nn.Linear(static_channels, attention_dim, bias=False)
+        self.T = nn.Linear(dynamic_channels, attention_dim)
+        self.v = nn.Linear(attention_dim, 1, bias=False)
+
+
 class StepwiseMonotonicAttention(nn.Module):
     kind = "SMA"
 

@@ -11,6 +11,8 @@
 // position j and reduced with wave shuffles; the encoder memory rows (E floats) are read
 // 16 B per lane, fully coalesced, once per step.  Positions whose weight is exactly 0 are
 // skipped in the context sum (SMA alignments are sparse early on; 0*x contributes nothing).
+#include <algorithm>
+
 #include "kernels.h"
 
 #ifdef T2_STAMPS
@@ -1344,6 +1346,410 @@ __global__ __launch_bounds__(NTB) void attention_gmm_step_bwd_kernel(AttnBwdDesc
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// DynamicConvolutionAttention (attention.py:195-289).  Per step, with a = previous alignment (one-hot at 0 first):
+//   hq = tanh(W h + bW) ; G = V hq -> 8 dynamic filters of 21 taps            (W h arrives as the LSTM kernel's partials)
+//   f_jc = sum_k F[c][k] a[j+k-10] ; g_jc = sum_k G[c][k] a[j+k-10]
+//   prior_j = sum_m P[m] a[j+m-10] ; p_j = log(max(prior_j, 1e-6))
+//   e_j = v . tanh(U f_j + T g_j + bT) + p_j ; w = softmax(mask(e)) ; ctx = w . memory
+// One workgroup per (b, stream).  LDS: padded alignment, filters, the [T_in][16] feature tile, U|T rows at pitch 17.
+// ---------------------------------------------------------------------------------------------
+constexpr int kDcaCK = kDcaC * kDcaK, kDcaUT = 2 * kDcaC + 1;          // 168 filter taps; pitch of a [U row | T row]
+
+__global__ __launch_bounds__(NT) void attention_dca_step_fwd_kernel(AttnStepDesc d) {
+    const AttnStream& st = d.st[blockIdx.y];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int Tin = st.Tin, A = d.A, E = d.E;
+    const int Tp = (Tin + 3) & ~3, TwP = (Tin + 2 * kDcaPad + 3) & ~3;
+    const int nd = E / 4, nh = NT / nd;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* hq = smem;                       // [A]
+    float* e = hq + A;                      // [Tp]
+    float* an = e + Tp;                     // [Tp]
+    float* red = an + Tp;                   // [4*NT]
+    float* cred = red + 4 * NT;             // [nh*E]
+    float* apad = cred + nh * E;            // [TwP]  apad[i] = a_prev[i - 10]
+    float* G = apad + TwP;                  // [168]
+    float* Fw = G + kDcaCK;                 // [168]
+    float* fg = Fw + kDcaCK;                // [Tin][16]  f (8) | g (8)
+    float* UT = fg + Tp * 16;               // [A][17]    U row (8) | T row (8)
+    float* bT = UT + A * kDcaUT;            // [A]
+    float* vS = bT + A;                     // [A]
+    float* Pf = vS + A;                     // [12]
+
+    // ---- W h + bW from the partials, tanh
+    {
+        const int a4n = A / 4, ng = NT / a4n;
+        const int pg = tid / a4n, a4 = (tid % a4n) * 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* p = st.qpart + (long)b * A + a4;
+        const long ps = (long)d.B * A;
+#pragma unroll 4
+        for (int i = pg; i < st.nparts; i += ng) acc += *reinterpret_cast<const f32x4*>(p + (long)i * ps);
+        *reinterpret_cast<f32x4*>(red + pg * A + a4) = acc;
+        for (int i = tid; i < A * 2 * kDcaC; i += NT) {
+            const int a = i / (2 * kDcaC), c = i % (2 * kDcaC);
+            UT[a * kDcaUT + c] = c < kDcaC ? st.dca.U[a * kDcaC + c] : st.dca.T[a * kDcaC + c - kDcaC];
+        }
+        for (int a = tid; a < A; a += NT) { bT[a] = st.dca.bT[a]; vS[a] = st.dca.v[a]; }
+        for (int i = tid; i < kDcaCK; i += NT) Fw[i] = st.dca.F[i];
+        if (tid < kDcaP) Pf[tid] = st.dca.P[tid];
+        for (int i = tid; i < TwP; i += NT) {
+            const int j = i - kDcaPad;
+            apad[i] = (j >= 0 && j < Tin) ? (st.a_prev ? st.a_prev[(long)b * st.lda_prev + j] : (j == 0 ? 1.f : 0.f)) : 0.f;
+        }
+        __syncthreads();
+        if (tid < A) {
+            float sum = 0.f;
+            const int used = st.nparts < ng ? st.nparts : ng;
+            for (int h2 = 0; h2 < used; ++h2) sum += red[h2 * A + tid];
+            sum += st.dca.bW[tid];
+            if (st.q_out) st.q_out[(long)b * st.ldq_out + tid] = sum;
+            hq[tid] = tanhf(sum);
+        }
+    }
+    __syncthreads();
+    for (int i = wave; i < kDcaCK; i += NT / 64) {                       // dynamic filters G = V hq
+        float sum = 0.f;
+        for (int a = lane; a < A; a += 64) sum += st.dca.V[(long)i * A + a] * hq[a];
+        sum = wave_sum(sum);
+        if (lane == 0) G[i] = sum;
+    }
+    __syncthreads();
+    for (int i = tid; i < Tin * kDcaC; i += NT) {                        // static and dynamic features
+        const int j = i / kDcaC, c = i % kDcaC;
+        float f = 0.f, g = 0.f;
+        for (int k = 0; k < kDcaK; ++k) { const float x = apad[j + k]; f += Fw[c * kDcaK + k] * x; g += G[c * kDcaK + k] * x; }
+        fg[j * 16 + c] = f; fg[j * 16 + kDcaC + c] = g;
+    }
+    __syncthreads();
+    // ---- energies: 16 lanes per position
+    {
+        const int gid = tid >> 4, sub = tid & 15;
+        for (int j = gid; j < Tp; j += NT / 16) {
+            float sum = 0.f;
+            if (j < Tin) {
+                float x[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) x[c] = fg[j * 16 + c];
+                for (int a0 = sub * 4; a0 < A; a0 += 64) {
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const int a = a0 + c4;
+                        float u = bT[a];
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) u += UT[a * kDcaUT + c] * x[c];
+                        sum += vS[a] * tanhf(u);
+                    }
+                }
+            }
+            sum += __shfl_xor(sum, 8, 64); sum += __shfl_xor(sum, 4, 64);
+            sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 1, 64);
+            if (sub == 0 && j < Tin) {
+                float pr = 0.f;
+#pragma unroll
+                for (int m = 0; m < kDcaP; ++m) pr += Pf[m] * apad[j + m];
+                e[j] = sum + logf(fmaxf(pr, 1e-6f));
+            }
+        }
+    }
+    __syncthreads();
+    const int len = st.lengths ? st.lengths[b] : Tin;
+    float mx = -INFINITY;
+    for (int j = tid; j < Tin; j += NT) {
+        float ev = e[j];
+        if (j >= len) ev = d.mask_value;
+        e[j] = ev;
+        mx = fmaxf(mx, ev);
+    }
+    mx = block_reduce(mx, red, true);
+    float ssum = 0.f;
+    for (int j = tid; j < Tin; j += NT) { const float x = expf(e[j] - mx); e[j] = x; ssum += x; }
+    ssum = block_reduce(ssum, red, false);
+    const float inv = 1.0f / ssum;
+    for (int j = tid; j < Tin; j += NT) {
+        const float w = e[j] * inv;
+        an[j] = w;
+        st.a_out[(long)b * st.lda_out + j] = w;
+    }
+    __syncthreads();
+    {
+        const int h = tid / nd, dd = (tid % nd) * 4;
+        if (h < nh) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* mp = st.memory + (long)b * Tin * E + dd;
+#pragma unroll 8
+            for (int j = h; j < Tin; j += nh) acc += an[j] * *reinterpret_cast<const f32x4*>(mp + (long)j * E);
+            *reinterpret_cast<f32x4*>(cred + h * E + dd) = acc;
+        }
+        __syncthreads();
+        for (int c = tid; c < E; c += NT) {
+            float s2 = 0.f;
+            for (int h2 = 0; h2 < nh; ++h2) s2 += cred[h2 * E + c];
+            st.ctx1[(long)b * st.ldctx1 + c] = s2;
+            if (st.ctx2) st.ctx2[(long)b * st.ldctx2 + c] = s2;
+            if (st.ctx16) st.ctx16[(long)b * st.ldctx16 + c] = (__bf16)s2;
+            if (st.ctx16b) st.ctx16b[(long)b * st.ldctx16b + c] = (__bf16)s2;
+        }
+    }
+}
+
+// Backward of one DCA step (reverse time), one workgroup per (b, stream).  Per-item accumulators (dca_acc):
+// dv [A] | dbT [A] | dU [A][8] | dT [A][8] | dF [168] | dV [168][A]; dW / dbW go through the dq path.
+__global__ __launch_bounds__(NTB) void attention_dca_step_bwd_kernel(AttnBwdDesc d) {
+    const AttnBwdStream& st = d.st[blockIdx.y];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int Tin = st.Tin, A = d.A, E = d.E;
+    const int Tp = (Tin + 3) & ~3, TwP = (Tin + 2 * kDcaPad + 3) & ~3, AS = A + 4;
+    constexpr int NWV = NTB / 64, NPG2 = NTB / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dctx = smem;                     // [E]
+    float* hq = dctx + E;                   // [A]
+    float* g = hq + A;                      // [Tp]
+    float* wS = g + Tp;                     // [Tp]
+    float* de = wS + Tp;                    // [Tp]
+    float* apad = de + Tp;                  // [TwP]
+    float* dprP = apad + TwP;               // [TwP]      dprP[i] = d(prior)_{i-10}, zero padded
+    float* G = dprP + TwP;                  // [168]
+    float* Fw = G + kDcaCK;                 // [168]
+    float* dGs = Fw + kDcaCK;               // [168]
+    float* fg = dGs + kDcaCK;               // [Tp][16]
+    float* dfgP = fg + Tp * 16;             // [TwP][16]  d(f|g)_{i-10}, zero padded rows
+    float* UT = dfgP + TwP * 16;            // [A][17]
+    float* bT = UT + A * kDcaUT;            // [A]
+    float* vS = bT + A;                     // [A]
+    float* Pf = vS + A;                     // [12]
+    float* red2 = Pf + 12;                  // [16]
+    float* S = red2 + 16;                   // [NPG2][AS]  s tile of a chunk; later the dv / dbT group partials and dwcat partials
+    float* acc0 = st.dca_acc + (long)b * dca_acc_floats(A);
+    float* acc_dv = acc0; float* acc_dbT = acc0 + A; float* acc_dU = acc0 + 2 * A; float* acc_dT = acc_dU + A * kDcaC;
+    float* acc_dF = acc_dT + A * kDcaC; float* acc_dV = acc_dF + kDcaCK;
+
+    for (int c = tid; c < E; c += NTB) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) if (st.dctx[i]) v += st.dctx[i][(long)b * st.lddctx[i] + c];
+        if (st.part && !d.first) {
+            const float* p = st.part + (long)b * st.ldpart + st.part_col + c;
+            float pv[8];
+#pragma unroll
+            for (int z = 0; z < 8; ++z) pv[z] = z < st.nparts ? p[(long)z * st.part_stride] : 0.f;
+            float acc = 0.f;
+#pragma unroll
+            for (int z = 0; z < 8; ++z) acc += pv[z];
+            v += acc;
+        }
+        dctx[c] = v;
+        st.dctx_out[(long)b * st.lddctx_out + c] = v;
+    }
+    for (int a = tid; a < A; a += NTB) { hq[a] = tanhf(st.q[(long)b * st.ldq + a]); bT[a] = st.dca.bT[a]; vS[a] = st.dca.v[a]; }
+    for (int j = tid; j < Tin; j += NTB) wS[j] = st.w[(long)b * st.ldw + j];
+    for (int i = tid; i < A * 2 * kDcaC; i += NTB) {
+        const int a = i / (2 * kDcaC), c = i % (2 * kDcaC);
+        UT[a * kDcaUT + c] = c < kDcaC ? st.dca.U[a * kDcaC + c] : st.dca.T[a * kDcaC + c - kDcaC];
+    }
+    for (int i = tid; i < kDcaCK; i += NTB) Fw[i] = st.dca.F[i];
+    if (tid < kDcaP) Pf[tid] = st.dca.P[tid];
+    for (int i = tid; i < TwP; i += NTB) {
+        const int j = i - kDcaPad;
+        apad[i] = (j >= 0 && j < Tin) ? (st.a_prev ? st.a_prev[(long)b * st.lda_prev + j] : (j == 0 ? 1.f : 0.f)) : 0.f;
+        dprP[i] = 0.f;
+    }
+    for (int i = tid; i < TwP * 16; i += NTB) dfgP[i] = 0.f;
+    __syncthreads();
+    for (int i = wave; i < kDcaCK; i += NWV) {                           // dynamic filters recomputed
+        float sum = 0.f;
+        for (int a = lane; a < A; a += 64) sum += st.dca.V[(long)i * A + a] * hq[a];
+        sum = wave_sum(sum);
+        if (lane == 0) G[i] = sum;
+    }
+    {   // g_j = dctx . memory_j + dalign_j + carry_j
+        constexpr int U = 4;
+        for (int j0 = wave; j0 < Tin; j0 += NWV * U) {
+            float sum[U] = {0.f, 0.f, 0.f, 0.f};
+            for (int c = lane * 4; c < E; c += 256) {
+                const f32x4 dc = *reinterpret_cast<const f32x4*>(dctx + c);
+                f32x4 mv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) mv[u] = *reinterpret_cast<const f32x4*>(st.memory + ((long)b * Tin + min(j0 + u * NWV, Tin - 1)) * E + c);
+#pragma unroll
+                for (int u = 0; u < U; ++u) sum[u] += mv[u][0] * dc[0] + mv[u][1] * dc[1] + mv[u][2] * dc[2] + mv[u][3] * dc[3];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + u * NWV;
+                const float tot = wave_sum(sum[u]);
+                if (lane == 0 && j < Tin) {
+                    float gs = tot;
+                    if (st.dalign) gs += st.dalign[(long)b * st.lddalign + j];
+                    if (!d.first) gs += st.carry[(long)b * Tin + j];
+                    g[j] = gs;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < Tin * kDcaC; i += NTB) {                       // features recomputed
+        const int j = i / kDcaC, c = i % kDcaC;
+        float f = 0.f, gg = 0.f;
+        for (int k = 0; k < kDcaK; ++k) { const float x = apad[j + k]; f += Fw[c * kDcaK + k] * x; gg += G[c * kDcaK + k] * x; }
+        fg[j * 16 + c] = f; fg[j * 16 + kDcaC + c] = gg;
+    }
+    {   // softmax backward, prior backward
+        float part = 0.f;
+        for (int j = tid; j < Tin; j += NTB) part += wS[j] * g[j];
+        part = wave_sum(part);
+        if (lane == 0) red2[wave] = part;
+        __syncthreads();
+        float sdot = 0.f;
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) sdot += red2[i];
+        for (int j = tid; j < Tin; j += NTB) {
+            const float dej = wS[j] * (g[j] - sdot);
+            de[j] = dej;
+            float pr = 0.f;
+#pragma unroll
+            for (int m = 0; m < kDcaP; ++m) pr += Pf[m] * apad[j + m];
+            dprP[j + kDcaPad] = pr >= 1e-6f ? dej / pr : 0.f;             // log(clamp_min(prior, 1e-6))
+        }
+    }
+    __syncthreads();
+
+    // ---- energies backward in chunks of NPG2 positions: s_ja = de_j v_a (1 - tanh(u_ja)^2) through an LDS tile
+    const int gid = tid >> 4, sub = tid & 15;
+    float dv[4][4], dbt[4][4], dUT[2 * kDcaC * 256 / NTB];               // A <= 256: A*16 outputs over NTB threads
+    constexpr int NUT = 2 * kDcaC * 256 / NTB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { dv[i][c] = 0.f; dbt[i][c] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < NUT; ++k) dUT[k] = 0.f;
+    for (int j0 = 0; j0 < Tin; j0 += NPG2) {
+        const int j = j0 + gid;
+        const bool valid = j < Tin;
+        const int jc = valid ? j : Tin - 1;
+        const float dej = valid ? de[jc] : 0.f;
+        float x[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) x[c] = fg[jc * 16 + c];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int a0 = sub * 4 + 64 * i;
+            if (a0 < A) {
+                f32x4 sv;
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const int a = a0 + c4;
+                    float u = bT[a];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) u += UT[a * kDcaUT + c] * x[c];
+                    const float th = tanhf(u);
+                    const float sa = dej * vS[a] * (1.0f - th * th);
+                    dv[i][c4] += dej * th;
+                    dbt[i][c4] += sa;
+                    sv[c4] = sa;
+                }
+                *reinterpret_cast<f32x4*>(S + gid * AS + a0) = sv;
+            }
+        }
+        __syncthreads();
+        const int nj = min(NPG2, Tin - j0);
+#pragma unroll
+        for (int k = 0; k < NUT; ++k) {                                  // dU | dT: thread-owned outputs (a, c)
+            const int o = tid + k * NTB;
+            if (o < A * 16) {
+                const int a = o >> 4, c = o & 15;
+                float sum = dUT[k];
+                for (int jj = 0; jj < nj; ++jj) sum += S[jj * AS + a] * fg[(j0 + jj) * 16 + c];
+                dUT[k] = sum;
+            }
+        }
+        {   // d(f|g) of this chunk: one output (jj, c) per thread
+            const int jj = tid >> 4, c = tid & 15;
+            if (jj < nj) {
+                float sum = 0.f;
+                for (int a = 0; a < A; ++a) sum += UT[a * kDcaUT + c] * S[jj * AS + a];
+                dfgP[(j0 + jj + kDcaPad) * 16 + c] = sum;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < NUT; ++k) {
+        const int o = tid + k * NTB;
+        if (o < A * 16) {
+            const int a = o >> 4, c = o & 15;
+            float* p = c < kDcaC ? acc_dU + a * kDcaC + c : acc_dT + a * kDcaC + c - kDcaC;
+            *p = (d.first ? 0.f : *p) + dUT[k];
+        }
+    }
+    // dv, dbT: reduce the position groups through the (now free) tile
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int a0 = sub * 4 + 64 * i;
+            if (a0 < A) {
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) S[gid * AS + a0 + c4] = pass == 0 ? dv[i][c4] : dbt[i][c4];
+            }
+        }
+        __syncthreads();
+        for (int a = tid; a < A; a += NTB) {
+            float sum = 0.f;
+            for (int k = 0; k < NPG2; ++k) sum += S[k * AS + a];
+            float* p = (pass == 0 ? acc_dv : acc_dbT) + a;
+            *p = (d.first ? 0.f : *p) + sum;
+        }
+        __syncthreads();
+    }
+    // dF (accumulated) and dG (this step's dynamic-filter gradient)
+    for (int it = tid; it < 2 * kDcaCK; it += NTB) {
+        const int which = it / kDcaCK, ck = it % kDcaCK, c = ck / kDcaK, k = ck % kDcaK;
+        float sum = 0.f;
+        for (int j = 0; j < Tin; ++j) sum += dfgP[(j + kDcaPad) * 16 + which * kDcaC + c] * apad[j + k];
+        if (which == 0) { float* p = acc_dF + ck; *p = (d.first ? 0.f : *p) + sum; }
+        else dGs[ck] = sum;
+    }
+    // gradient on the previous alignment: prior conv + static + dynamic convs, 8 partials per position
+    float* tmp = S;                                                       // [8][Tp]
+    if (st.a_prev) {
+        for (int it = tid; it < kDcaC * Tin; it += NTB) {
+            const int c = it / Tin, i = it % Tin;
+            float sum = 0.f;
+            if (c == 0) {
+#pragma unroll
+                for (int m = 0; m < kDcaP; ++m) sum += Pf[m] * dprP[i - m + 2 * kDcaPad];
+            }
+            for (int k = 0; k < kDcaK; ++k) {
+                const float* row = dfgP + (i - k + 2 * kDcaPad) * 16;
+                sum += Fw[c * kDcaK + k] * row[c] + G[c * kDcaK + k] * row[kDcaC + c];
+            }
+            tmp[c * Tp + i] = sum;
+        }
+    }
+    __syncthreads();
+    if (st.a_prev) {
+        for (int i = tid; i < Tin; i += NTB) {
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < kDcaC; ++c) sum += tmp[c * Tp + i];
+            st.carry[(long)b * Tin + i] = sum;
+        }
+    }
+    // through V and tanh to dq; dV accumulated
+    for (int a = tid; a < A; a += NTB) {
+        float dh = 0.f;
+        for (int i = 0; i < kDcaCK; ++i) dh += st.dca.V[(long)i * A + a] * dGs[i];
+        st.dq_out[(long)b * st.lddq_out + a] = dh * (1.0f - hq[a] * hq[a]);
+    }
+    for (int i = tid; i < kDcaCK * A; i += NTB) {
+        float* p = acc_dV + i;
+        *p = (d.first ? 0.f : *p) + dGs[i / A] * hq[i % A];
+    }
+}
+
 }  // namespace
 
 size_t attention_fwd_smem(const AttnStepDesc& d, bool with_pa) {
@@ -1362,6 +1768,25 @@ size_t attention_fwd_smem(const AttnStepDesc& d, bool with_pa) {
 
 int attention_step_fwd(const AttnStepDesc& din, hipStream_t s) {
     AttnStepDesc d = din;
+    if (d.kind == 3) {                                               // DCA
+        T2_REQUIRE(d.nstreams >= 1 && d.nstreams <= 2 && d.A % 4 == 0 && d.A <= 256 && NT % (d.A / 4) == 0 && d.E % 4 == 0 && NT % (d.E / 4) == 0,
+                   "attention_step (DCA): A=%d E=%d unsupported", d.A, d.E);
+        int Tmax = 0;
+        for (int i = 0; i < d.nstreams; ++i) {
+            Tmax = d.st[i].Tin > Tmax ? d.st[i].Tin : Tmax;
+            const DcaWeights& w = d.st[i].dca;
+            T2_REQUIRE(d.st[i].qpart && w.bW && w.V && w.F && w.U && w.T && w.bT && w.v && w.P, "attention_step (DCA): missing weights");
+        }
+        const int Tp = (Tmax + 3) & ~3, TwP = (Tmax + 2 * kDcaPad + 3) & ~3;
+        const size_t smem = ((size_t)d.A + 2 * Tp + 4 * NT + (size_t)(NT / (d.E / 4)) * d.E + TwP + 2 * kDcaCK + (size_t)Tp * 16 +
+                             (size_t)d.A * kDcaUT + 2 * d.A + 12) * sizeof(float);
+        T2_REQUIRE(smem <= 160 * 1024, "attention_step (DCA): T_in too long for LDS (%zu bytes)", smem);
+        if (smem > 64 * 1024)
+            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_dca_step_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(attention_dca_step_fwd_kernel, dim3(d.B, d.nstreams), dim3(NT), smem, s, d);
+        T2_LAUNCH_CHECK();
+        return 0;
+    }
     if (d.kind == 2) {                                               // GMM
         T2_REQUIRE(d.nstreams >= 1 && d.nstreams <= 2 && d.A % 4 == 0 && d.A <= 256 && NT % (d.A / 4) == 0 && d.E % 4 == 0 && NT % (d.E / 4) == 0,
                    "attention_step (GMM): A=%d E=%d unsupported", d.A, d.E);
@@ -1413,6 +1838,22 @@ int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s) {
     T2_REQUIRE(d.A % 4 == 0 && d.A <= 256 && d.E % 4 == 0, "attention_bwd: A=%d E=%d unsupported", d.A, d.E);
     int Tmax = 0;
     for (int i = 0; i < d.nstreams; ++i) Tmax = d.st[i].Tin > Tmax ? d.st[i].Tin : Tmax;
+    if (d.kind == 3) {                                               // DCA
+        for (int i = 0; i < d.nstreams; ++i) {
+            const DcaWeights& w = d.st[i].dca;
+            T2_REQUIRE(d.st[i].w && d.st[i].dca_acc && w.V && w.F && w.U && w.T && w.bT && w.v && w.P, "attention_bwd (DCA): missing buffers");
+        }
+        const int Tp = (Tmax + 3) & ~3, TwP = (Tmax + 2 * kDcaPad + 3) & ~3;
+        const size_t tile = std::max((size_t)(NTB / 16) * (d.A + 4), (size_t)kDcaC * Tp);
+        const size_t smem = ((size_t)d.E + d.A + 3 * Tp + 2 * TwP + 3 * kDcaCK + (size_t)Tp * 16 + (size_t)TwP * 16 + (size_t)d.A * kDcaUT +
+                             2 * d.A + 12 + 16 + tile) * sizeof(float);
+        T2_REQUIRE(smem <= 160 * 1024, "attention_bwd (DCA): T_in too long for LDS (%zu bytes)", smem);
+        if (smem > 64 * 1024)
+            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_dca_step_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(attention_dca_step_bwd_kernel, dim3(d.B, d.nstreams), dim3(NTB), smem, s, d);
+        T2_LAUNCH_CHECK();
+        return 0;
+    }
     if (d.kind == 2) {                                               // GMM
         for (int i = 0; i < d.nstreams; ++i)
             T2_REQUIRE(d.st[i].w && d.st[i].gmm_w2 && d.st[i].gmm_b2 && d.st[i].mu && d.st[i].mu_carry && d.st[i].dw2_acc && d.st[i].db2_acc,

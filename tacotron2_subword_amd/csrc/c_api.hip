@@ -113,7 +113,7 @@ int check_dims(const t2_dims& d) {
     T2_REQUIRE(d.prenet_dim % 64 == 0 && d.enc_dim % 64 == 0 && d.att_rnn_dim % 64 == 0 && d.dec_rnn_dim % 64 == 0,
                "prenet/encoder/rnn dims must be multiples of 64 (got %d %d %d %d)", d.prenet_dim, d.enc_dim, d.att_rnn_dim, d.dec_rnn_dim);
     T2_REQUIRE(d.att_dim % 4 == 0 && d.att_dim <= 256, "attention_dim %d unsupported", d.att_dim);
-    T2_REQUIRE(d.attention_kind == T2_ATTN_SMA || d.attention_kind == T2_ATTN_LSA || d.attention_kind == T2_ATTN_FWD2 || d.attention_kind == T2_ATTN_GMM, "unknown attention kind %d", d.attention_kind);
+    T2_REQUIRE(d.attention_kind == T2_ATTN_SMA || d.attention_kind == T2_ATTN_LSA || d.attention_kind == T2_ATTN_FWD2 || d.attention_kind == T2_ATTN_GMM || d.attention_kind == T2_ATTN_DCA, "unknown attention kind %d", d.attention_kind);
     return 0;
 }
 
@@ -247,6 +247,12 @@ int cast_shadows(const t2_dims& d, const t2_decoder_weights& w, const Sizes& z, 
     return 0;
 }
 
+DcaWeights dca_weights(const t2_attention_weights& aw) {
+    DcaWeights w{};
+    w.bW = aw.mlp_b1; w.V = aw.mlp_w2; w.F = aw.loc_conv; w.U = aw.loc_dense; w.T = aw.dca_T; w.bT = aw.dca_bT; w.v = aw.v; w.P = aw.dca_P;
+    return w;
+}
+
 int att_lstm_step(const Dec& c, int t) {
     const Sizes& z = c.z; const t2_decoder_layout& L = c.L;
     LstmStepDesc d{};
@@ -316,7 +322,9 @@ int attention_step(const Dec& c, int t) {
         st.lengths = s ? c.len_sub : c.len;
         st.a_prev = t > 0 ? al + (long)(t - 1) * Tin : nullptr; st.lda_prev = ldA;
         st.a_out = al + (long)t * Tin; st.lda_out = ldA;
-        if (d.kind == T2_ATTN_GMM) {
+        if (d.kind == T2_ATTN_DCA) {
+            st.dca = dca_weights(aw);
+        } else if (d.kind == T2_ATTN_GMM) {
             float* mu = c.P(s ? L.wcums : L.wcum);                    // [T,B,kGmmPad]
             st.mu_prev = t > 0 ? mu + c.R(t - 1) * kGmmPad : nullptr; st.mu_out = mu + c.R(t) * kGmmPad;
             st.gmm_b1 = aw.mlp_b1; st.gmm_w2 = aw.mlp_w2; st.gmm_b2 = aw.mlp_b2;
@@ -337,7 +345,8 @@ int attention_step(const Dec& c, int t) {
         st.site_noise = s ? T2_SITE_NOISE_SUB : T2_SITE_NOISE;
         st.idx_base = (uint32_t)(c.R(t) * Tin); st.idx_bstride = (uint32_t)Tin;          // logical [T,B,Tin]
     }
-    if (d.kind == T2_ATTN_GMM) d.kind = 2;                       // kernel-level kind (0 SMA, 1 LSA, 2 GMM)
+    if (d.kind == T2_ATTN_GMM) d.kind = 2;                       // kernel-level kind (0 SMA, 1 LSA, 2 GMM, 3 DCA)
+    else if (d.kind == T2_ATTN_DCA) d.kind = 3;
     ProfScope ps(PK_ATTN_FWD, c.s);
     return attention_step_fwd(d, c.s);
 }
@@ -397,7 +406,7 @@ int projection(const Dec& c, const float* X, long ldx, int M, float* mel, long l
 
 int processed_memory(const Dec& c) {
     const Sizes& z = c.z;
-    if (c.d.attention_kind == T2_ATTN_GMM) return 0;               // purely location-based: memory_layer is never used
+    if (c.d.attention_kind == T2_ATTN_GMM || c.d.attention_kind == T2_ATTN_DCA) return 0;   // purely location-based: memory_layer is never used
     GemmDesc g = linear(c.memory, z.E, c.w.attn.wm, z.E, c.P(c.L.pm), z.A, z.B * z.Tin, z.A, z.E);
     T2_TRY(gemm(g, c.s));
     if (z.NS == 1) return 0;
@@ -432,8 +441,9 @@ void bwd_layout_of(const t2_dims& d, const Sizes& z, t2_decoder_bwd_layout* L) {
     L->carry = take((size_t)2 * z.B * z.Tin); L->carrys = take((size_t)2 * z.B * z.Tsub);   // ping-pong by step parity
     const bool lsa = d.attention_kind == T2_ATTN_LSA;          // LSA: cumulative-weight carry + per-item location-layer gradients
     const bool gmm = d.attention_kind == T2_ATTN_GMM;          // GMM: mean carry [B,8] + per-item db2 [B,16] / dW2 [B,3K*A]
+    const bool dca = d.attention_kind == T2_ATTN_DCA;          // DCA: all per-item accumulators in one block (dldense)
     const size_t ncv = lsa ? (size_t)z.B * d.loc_filters * 2 * d.loc_kernel : gmm ? (size_t)z.B * 16 : 0;
-    const size_t nds = lsa ? (size_t)z.B * z.A * d.loc_filters : gmm ? (size_t)z.B * 3 * kGmmK * z.A : 0;
+    const size_t nds = lsa ? (size_t)z.B * z.A * d.loc_filters : gmm ? (size_t)z.B * 3 * kGmmK * z.A : dca ? (size_t)z.B * dca_acc_floats(z.A) : 0;
     L->carryc = take(lsa ? (size_t)z.B * z.Tin : gmm ? (size_t)z.B * kGmmPad : 0); L->carrycs = take(lsa ? (size_t)z.B * z.Tsub : gmm ? (size_t)z.B * kGmmPad : 0);
     L->dlconv = take(ncv); L->dlconvs = take(ncv); L->dldense = take(nds); L->dldenses = take(nds);
     L->dcd = take((size_t)z.B * z.Hd); L->dca = take((size_t)z.B * z.Ha); L->dcas = take((size_t)z.B * z.Ha);
@@ -537,7 +547,11 @@ int att_bwd_step(const Bwd& c, int t) {
         if (t > 0) { st.a_prev = al + (long)(t - 1) * Tin; st.lda_prev = ldA; }
         const t2_attention_weights& aw = s ? c.w.attn_sub : c.w.attn;
         st.v = aw.v;
-        if (ab.kind == T2_ATTN_GMM) {
+        if (ab.kind == T2_ATTN_DCA) {
+            st.w = al + (long)t * Tin; st.ldw = ldA;
+            st.dca = dca_weights(aw);
+            st.dca_acc = c.S(s ? c.BL.dldenses : c.BL.dldense);
+        } else if (ab.kind == T2_ATTN_GMM) {
             st.w = al + (long)t * Tin; st.ldw = ldA;
             st.gmm_w2 = aw.mlp_w2; st.gmm_b2 = aw.mlp_b2;
             st.mu = c.W(s ? c.L.wcums : c.L.wcum) + c.R(t) * kGmmPad; st.ldmu = kGmmPad;
@@ -563,6 +577,7 @@ int att_bwd_step(const Bwd& c, int t) {
         st.dpm_acc = c.S(s ? c.BL.dpms : c.BL.dpm);
     }
     if (ab.kind == T2_ATTN_GMM) ab.kind = 2;                     // kernel-level kind
+    else if (ab.kind == T2_ATTN_DCA) ab.kind = 3;
     { ProfScope ps(PK_ATTN_BWD, c.s); T2_TRY(attention_step_bwd(ab, c.s)); }
     // 2. LSTM pointwise backward
     LstmBwdPointDesc p{};
@@ -804,8 +819,26 @@ int t2_decoder_backward(const t2_dims* dims_in, const t2_decoder_weights* w, con
         float* DQ = c.S(s ? BL.dqs : BL.dq);
         if (nsp == 2) T2_TRY(fold_halves(DQ, BT, z.A, c.s));               // dq row = partial 0 + partial 1
         T2_TRY(gemm(matmul_tn(c, DQ, 2 * z.A, DIN + hoff, z.WD, ag.wq, z.Ha, z.A, z.Ha, BT), c.s));
-        const bool gmm = dims->attention_kind == T2_ATTN_GMM;
-        if (gmm) {
+        const bool dcak = dims->attention_kind == T2_ATTN_DCA;
+        const bool gmm = dims->attention_kind == T2_ATTN_GMM || dcak;     // both: no processed-memory term
+        if (dcak) {
+            // W.weight went through the query-projection path above; W.bias = column sums of dq; the rest from the per-item
+            // accumulators dv | dbT | dU | dT | dF | dV (attention.hip)
+            T2_REQUIRE(ag.mlp_b1 && ag.mlp_w2 && ag.loc_conv && ag.loc_dense && ag.dca_T && ag.dca_bT && ag.v, "t2_decoder_backward: DCA gradient buffers missing");
+            T2_TRY(colsum(DQ, 2 * z.A, BT, z.A, ag.mlp_b1, nullptr, cws, c.s));
+            const size_t na = dca_acc_floats(z.A);
+            float* full = c.gemm_ws();                                   // [na] floats of the split-K scratch (idle here)
+            T2_REQUIRE(na * sizeof(float) <= c.gemm_ws_bytes(), "t2_decoder_backward: scratch too small");
+            T2_TRY(batch_sum(c.S(s ? BL.dldenses : BL.dldense), z.B, (int)na, full, c.s));
+            auto cp = [&](float* dst, size_t off, size_t n) { return hipMemcpyAsync(dst, full + off, n * sizeof(float), hipMemcpyDeviceToDevice, c.s); };
+            size_t off = 0;
+            T2_CHECK_HIP(cp(ag.v, off, z.A)); off += z.A;
+            T2_CHECK_HIP(cp(ag.dca_bT, off, z.A)); off += z.A;
+            T2_CHECK_HIP(cp(ag.loc_dense, off, (size_t)z.A * kDcaC)); off += (size_t)z.A * kDcaC;
+            T2_CHECK_HIP(cp(ag.dca_T, off, (size_t)z.A * kDcaC)); off += (size_t)z.A * kDcaC;
+            T2_CHECK_HIP(cp(ag.loc_conv, off, kDcaC * kDcaK)); off += kDcaC * kDcaK;
+            T2_CHECK_HIP(cp(ag.mlp_w2, off, (size_t)kDcaC * kDcaK * z.A));
+        } else if (gmm) {
             // mlp.0.weight was handled as the query projection above; mlp.0.bias = column sums of dq; second layer from
             // the per-item accumulators; memory_layer takes no part in the arithmetic (its gradient is None in the reference)
             T2_REQUIRE(ag.mlp_b1 && ag.mlp_w2 && ag.mlp_b2, "t2_decoder_backward: GMM needs mlp_b1 / mlp_w2 / mlp_b2 gradient buffers");

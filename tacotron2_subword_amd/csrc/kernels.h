@@ -96,6 +96,17 @@ int cast_rows_bf16(const float* src, long ld_src, __bf16* dst, long ld_dst, int 
 int cast_transpose_bf16(const float* src, long ld_src, __bf16* dst, long ld_dst, int R, int C, hipStream_t s);
 
 // ------------------------------------------------------------------ attention (attention.hip)
+// DynamicConvolutionAttention (attention.py:195-289): 8 static + 8 dynamic channels, 21 taps, 11-tap prior
+constexpr int kDcaC = 8, kDcaK = 21, kDcaP = 11, kDcaPad = (kDcaK - 1) / 2;
+struct DcaWeights {                       // wq / qpart of the stream carry W (Linear Ha->A)
+    const float* bW;                      // W.bias [A]
+    const float* V;                       // V.weight [C*K, A]
+    const float* F;                       // F.weight [C, 1, K]
+    const float* U;                       // U.weight [A, C]
+    const float* T; const float* bT;      // T.weight [A, C], T.bias [A]
+    const float* v;                       // v.weight [1, A]
+    const float* P;                       // prior buffer [11] (already flipped, attention.py:221)
+};
 struct AttnStream {
     const float* query; long ldq;         // [B,A] processed query (W_q h), or null when qpart is given
     const float* qpart; int nparts;       // [nparts][B][A] partial queries from lstm_step_fwd (summed in order)
@@ -119,6 +130,7 @@ struct AttnStream {
     // GMM attention (kind 2): wq / qpart carry mlp.0 (Linear Ha->A); second layer and state below
     const float* gmm_b1; const float* gmm_w2; const float* gmm_b2;   // [A], [3K, A], [3K]
     const float* mu_prev; float* mu_out;  // [B, kGmmPad] mixture means before / after this step (mu_prev null at t=0 -> 0)
+    DcaWeights dca;                       // kind 3
 };
 constexpr int kGmmK = 5, kGmmPad = 8;     // mixtures (attention.py:409), row pitch of the mean buffers
 struct AttnStepDesc {
@@ -157,7 +169,12 @@ struct AttnBwdStream {
     const float* mu; long ldmu;            // [B, kGmmPad] mixture means of step t
     float* mu_carry;                       // [B, kGmmPad] gradient on the means flowing in from step t+1 (in/out)
     float* dw2_acc; float* db2_acc;        // [B, 3K*A], [B, 16] per-item accumulators
+    // DCA only (kind 3): q = saved pre-activation of W (incl. bias); w = weights of step t; a_prev = weights of step t-1
+    // (null at t=0 -> one-hot at 0); carry = gradient on a_{t} from step t+1 (in/out)
+    DcaWeights dca;
+    float* dca_acc;                        // [B][A (dv) + A (dbT) + A*C (dU) + A*C (dT) + C*K (dF) + C*K*A (dV)] per-item accumulators
 };
+__host__ __device__ inline size_t dca_acc_floats(int A) { return (size_t)2 * A + 2 * (size_t)A * kDcaC + kDcaC * kDcaK + (size_t)kDcaC * kDcaK * A; }
 struct AttnBwdDesc { AttnBwdStream st[2]; int nstreams; int B, A, E; int first; int kind, F, Kc; int nsplit; };   // nsplit: SMA only
 int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s);
 

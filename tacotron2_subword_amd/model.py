@@ -20,7 +20,8 @@ from torch import nn
 from . import _lib as L
 from . import blocks
 from . import ops
-from .attention import ForwardAttentionV2, GMMAttention, LocationSensitiveAttention, StepwiseMonotonicAttention
+from .attention import (DynamicConvolutionAttention, ForwardAttentionV2, GMMAttention, LocationSensitiveAttention,
+                        StepwiseMonotonicAttention)
 from .layers import ConvNorm, LinearNorm
 from .utils import get_mask_from_lengths, to_gpu
 
@@ -118,6 +119,7 @@ class _DecoderFn(torch.autograd.Function):
     def forward(ctx, memory, memory_sub, mels, mem_lengths, sub_lengths, cfg, *params):
         dec, keys = cfg["decoder"], cfg["keys"]
         P = {"decoder." + k: p.detach() for k, p in zip(keys, params)}
+        P.update({"decoder." + k: v for k, v in dec.named_buffers()})          # DCA prior taps
         dims = dec.dims
         W = L.decoder_weights(P, dims.attention_kind, single=dec.single)
         memory, mels = memory.contiguous(), mels.contiguous()
@@ -168,12 +170,13 @@ class Decoder(nn.Module):
         # The reference builds attention_layer_bert only for SMA and then uses it unconditionally
         # (model.py:158-191 vs :261,356); here both streams always get their module.
         att_cls = {"StepwiseMonotonicAttention": StepwiseMonotonicAttention, "ForwardAttentionV2": ForwardAttentionV2,
-                   "GMMAttention": GMMAttention,
+                   "GMMAttention": GMMAttention, "DynamicConvolutionAttention": DynamicConvolutionAttention,
                    "LSA": LocationSensitiveAttention, "LocationSensitiveAttention": LocationSensitiveAttention}.get(hp.attention)
         if att_cls is None:
-            raise NotImplementedError(f"attention '{hp.attention}' is not built yet (SURVEY.md §8f N1: "
-                                      "DynamicConvolutionAttention); use StepwiseMonotonicAttention, LSA, ForwardAttentionV2 or GMMAttention")
-        print({"SMA": "Use SMA", "LSA": "Use LSA", "FWD2": "Use ForwardAttention", "GMM": "Use GMMA"}[att_cls.kind])      # model.py:159-191
+            raise ValueError(f"unknown attention '{hp.attention}': StepwiseMonotonicAttention, LSA, ForwardAttentionV2, "
+                             "GMMAttention or DynamicConvolutionAttention")
+        print({"SMA": "Use SMA", "LSA": "Use LSA", "FWD2": "Use ForwardAttention", "GMM": "Use GMMA",
+               "DCA": "Use DCA"}[att_cls.kind])                          # model.py:159-191
         args = (Ha, E, hp.attention_dim, hp.attention_location_n_filters, hp.attention_location_kernel_size)
         self.attention_layer = att_cls(*args)
         if not single:
@@ -200,6 +203,7 @@ class Decoder(nn.Module):
 
     def _weights(self):
         P = {"decoder." + k: v.detach() for k, v in self.named_parameters()}
+        P.update({"decoder." + k: v for k, v in self.named_buffers()})           # DCA prior taps
         return P, L.decoder_weights(P, self.dims.attention_kind, single=self.single)
 
     # -- reference surface -----------------------------------------------------------------

@@ -98,7 +98,8 @@ def build_reference(ref_model, ref_attention, ref_hparams, attention, seed=1234)
     if attention != "StepwiseMonotonicAttention":
         # model.py:158-191 builds attention_layer_bert only for SMA and then uses it unconditionally (:261,356): the
         # harness supplies the missing module of the same class
-        cls = {"ForwardAttentionV2": ref_attention.ForwardAttentionV2, "GMMAttention": ref_attention.GMMAttention}.get(
+        cls = {"ForwardAttentionV2": ref_attention.ForwardAttentionV2, "GMMAttention": ref_attention.GMMAttention,
+               "DynamicConvolutionAttention": ref_attention.DynamicConvolutionAttention}.get(
             attention, ref_attention.LocationSensitiveAttention)
         m.decoder.attention_layer_bert = cls(
             hps.attention_rnn_dim, hps.encoder_embedding_dim, hps.attention_dim,
@@ -259,6 +260,7 @@ def main():
     gen_inference(refs, LSA, "lsa_infer", 21, 11)
     gen_fa2(refs)
     gen_gmm(refs)
+    gen_dca(refs)
 
 
 def gen_fa2(refs):
@@ -275,8 +277,21 @@ def gen_gmm(refs):
     gen_forward(refs, GMM, "gmm_small_train", 3, 13, 8, 12, training=True, with_grads=True)
 
 
+def gen_dca(refs):
+    """DynamicConvolutionAttention; `python make_golden.py dca` writes only these.  Its init_attention
+    hard-codes `.cuda()` (attention.py:234); on this GPU-less box the harness makes Tensor.cuda the identity."""
+    DCA = "DynamicConvolutionAttention"
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    gen_forward(refs, DCA, "dca_small_eval", 2, 13, 8, 12, training=False)
+    gen_forward(refs, DCA, "dca_small_train", 3, 13, 8, 12, training=True, with_grads=True)
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["gmm"]:
+    if sys.argv[1:] == ["dca"]:
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        gen_dca(import_reference())
+    elif sys.argv[1:] == ["gmm"]:
         torch.manual_seed(0)
         torch.set_num_threads(8)
         gen_gmm(import_reference())

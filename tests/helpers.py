@@ -7,7 +7,7 @@ import torch
 from oracle import recipe
 from oracle import tacotron2_oracle as O
 
-SMA, LSA, FA2, GMM = "StepwiseMonotonicAttention", "LSA", "ForwardAttentionV2", "GMMAttention"
+SMA, LSA, FA2, GMM, DCA = "StepwiseMonotonicAttention", "LSA", "ForwardAttentionV2", "GMMAttention", "DynamicConvolutionAttention"
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 

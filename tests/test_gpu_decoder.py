@@ -8,7 +8,7 @@ import torch
 from oracle import recipe
 from oracle import tacotron2_oracle as O
 
-from helpers import FA2, GMM, LSA, SMA, hp_for, load_golden, maxabs, oracle_memories, tiny_hp, to_dev
+from helpers import DCA, FA2, GMM, LSA, SMA, hp_for, load_golden, maxabs, oracle_memories, tiny_hp, to_dev
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -32,7 +32,7 @@ def run_hip_decoder(env, P, hp, mem, mem_sub, tl, bl, mels, training=False, pren
     return dp
 
 
-@pytest.mark.parametrize("att,name", [(SMA, "sma_small_eval"), (LSA, "lsa_small_eval"), (SMA, "sma_baseline_eval"), (FA2, "fa2_small_eval"), (GMM, "gmm_small_eval")])
+@pytest.mark.parametrize("att,name", [(SMA, "sma_small_eval"), (LSA, "lsa_small_eval"), (SMA, "sma_baseline_eval"), (FA2, "fa2_small_eval"), (GMM, "gmm_small_eval"), (DCA, "dca_small_eval")])
 def test_teacher_forced_vs_golden(env, att, name):
     g = load_golden(name)
     B, Tin, Tsub, T, _ = (int(v) for v in g["meta"])
@@ -60,7 +60,7 @@ def test_teacher_forced_vs_golden(env, att, name):
     assert maxabs(dout[T - 1, :, :Hd], g["steplast_dec_h"]) < TOL
 
 
-@pytest.mark.parametrize("att", [SMA, LSA, FA2, GMM])
+@pytest.mark.parametrize("att", [SMA, LSA, FA2, GMM, DCA])
 @pytest.mark.parametrize("B", [1, 5, 33])
 def test_teacher_forced_tiny_vs_oracle(env, att, B):
     """Small dims, ragged lengths, batch sizes around the 32-row MFMA tile edge."""
@@ -175,7 +175,7 @@ def _edge_batch(hp, B, Tin, Tsub, T, lens_in, lens_sub):
     return x
 
 
-@pytest.mark.parametrize("att", [SMA, LSA, FA2, GMM])
+@pytest.mark.parametrize("att", [SMA, LSA, FA2, GMM, DCA])
 @pytest.mark.parametrize("case", ["one_frame", "one_position", "length_one_items", "long_memory", "batch_130"])
 def test_teacher_forced_edge_shapes(env, att, case):
     """Edge shapes of the decoder pass (tiny dims): a single frame, a single memory position, items whose valid

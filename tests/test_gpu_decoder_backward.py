@@ -9,7 +9,7 @@ import torch
 from oracle import recipe
 from oracle import tacotron2_oracle as O
 
-from helpers import FA2, GMM, LSA, SMA, hp_for, maxabs, oracle_memories, tiny_hp, to_dev
+from helpers import DCA, FA2, GMM, LSA, SMA, hp_for, maxabs, oracle_memories, tiny_hp, to_dev
 
 pytestmark = pytest.mark.gpu
 RTOL = 3e-4          # max-abs error relative to the largest reference entry of each gradient tensor
@@ -39,7 +39,7 @@ def hip_rnd(ops, L, hp, seed, B, T, Tin, Tsub):
 
 
 @pytest.mark.parametrize("cfg", ["tiny_eval", "tiny_train", "tiny_b33", "tiny_long", "tiny_T40", "tiny_one_frame", "tiny_long_memory", "default_train", "default_align"])
-@pytest.mark.parametrize("att", [SMA, LSA, FA2, GMM])
+@pytest.mark.parametrize("att", [SMA, LSA, FA2, GMM, DCA])
 def test_decoder_backward_vs_autograd(env, cfg, att):
     L, ops = env
     training = cfg in ("tiny_train", "default_train", "default_align", "tiny_b33", "tiny_long", "tiny_T40", "tiny_long_memory")
@@ -69,7 +69,7 @@ def test_decoder_backward_vs_autograd(env, cfg, att):
     rnd = hip_rnd(ops, L, hp, seed, B, T, Tin, Tsub) if training else None
 
     # ---- oracle: autograd, in fp32 (the reference's arithmetic) and in fp64 (ground truth for the tolerance)
-    dec_keys = ["decoder." + k for k in L.decoder_param_keys({SMA: L.ATTN_SMA, GMM: L.ATTN_GMM}.get(att, L.ATTN_LSA))]
+    dec_keys = ["decoder." + k for k in L.decoder_param_keys({SMA: L.ATTN_SMA, GMM: L.ATTN_GMM, DCA: L.ATTN_DCA}.get(att, L.ATTN_LSA))]
     g = torch.Generator().manual_seed(17)
     R_mel, R_gate = torch.randn(B, hp["n_mel_channels"], T, generator=g), torch.randn(B, T, generator=g)
     R_al, R_alb = torch.randn(B, T, Tin, generator=g), torch.randn(B, T, Tsub, generator=g)

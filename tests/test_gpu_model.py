@@ -7,7 +7,7 @@ import torch
 from oracle import recipe
 from oracle import tacotron2_oracle as O
 
-from helpers import FA2, GMM, LSA, SMA, hp_for, load_golden, maxabs
+from helpers import DCA, FA2, GMM, LSA, SMA, hp_for, load_golden, maxabs
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -26,7 +26,7 @@ def build_model(att, train=False):
     return m, hps
 
 
-@pytest.mark.parametrize("att,name", [(SMA, "sma_small_eval"), (LSA, "lsa_small_eval"), (SMA, "sma_baseline_eval"), (FA2, "fa2_small_eval"), (GMM, "gmm_small_eval")])
+@pytest.mark.parametrize("att,name", [(SMA, "sma_small_eval"), (LSA, "lsa_small_eval"), (SMA, "sma_baseline_eval"), (FA2, "fa2_small_eval"), (GMM, "gmm_small_eval"), (DCA, "dca_small_eval")])
 def test_forward_eval_vs_golden(att, name):
     g = load_golden(name)
     B, Tin, Tsub, T, _ = (int(v) for v in g["meta"])
@@ -40,7 +40,7 @@ def test_forward_eval_vs_golden(att, name):
         assert maxabs(v, g[k]) < TOL, k
 
 
-@pytest.mark.parametrize("att", [SMA, LSA, FA2, GMM])
+@pytest.mark.parametrize("att", [SMA, LSA, FA2, GMM, DCA])
 def test_backward_eval_mode_vs_oracle_autograd(att):
     """Whole-model gradients (embeddings, encoders, converters, decoder, postnet) in eval mode (BN
     running statistics, no dropout, no noise): HIP backward of every block vs the oracle's autograd."""
@@ -114,7 +114,7 @@ def test_training_step_runs_and_is_finite():
         assert moved == (not k.startswith("decoder.decoder_rnn_bert")), k
 
 
-@pytest.mark.parametrize("att", [SMA, LSA, FA2, GMM])
+@pytest.mark.parametrize("att", [SMA, LSA, FA2, GMM, DCA])
 def test_training_mode_full_model_vs_oracle(att):
     """Training mode end to end: BN batch statistics, conv/LSTM-state/prenet dropout and SMA noise drawn
     by the HIP RNG (exported through the C ABI and replayed through the oracle), loss, every parameter

@@ -9,7 +9,7 @@ import torch
 from oracle import recipe
 from oracle import tacotron2_oracle as O
 
-SMA, LSA, FA2, GMM = "StepwiseMonotonicAttention", "LSA", "ForwardAttentionV2", "GMMAttention"
+SMA, LSA, FA2, GMM, DCA = "StepwiseMonotonicAttention", "LSA", "ForwardAttentionV2", "GMMAttention", "DynamicConvolutionAttention"
 TOL = 2e-5      # oracle-vs-reference fp32 CPU, same torch kernels, different op grouping
 
 
@@ -27,7 +27,7 @@ def _maxabs(a, b):
     return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
 
 
-@pytest.mark.parametrize("att,name", [(SMA, "sma_small_eval"), (LSA, "lsa_small_eval"), (SMA, "sma_baseline_eval"), (FA2, "fa2_small_eval"), (GMM, "gmm_small_eval")])
+@pytest.mark.parametrize("att,name", [(SMA, "sma_small_eval"), (LSA, "lsa_small_eval"), (SMA, "sma_baseline_eval"), (FA2, "fa2_small_eval"), (GMM, "gmm_small_eval"), (DCA, "dca_small_eval")])
 def test_forward_eval(golden_dir, att, name):
     g = _load(golden_dir, name)
     B, Tin, Tsub, T, _ = g["meta"]
@@ -46,7 +46,7 @@ def test_forward_eval(golden_dir, att, name):
             assert _maxabs(trace[idx][field].numpy(), g[key]) < TOL, key
 
 
-@pytest.mark.parametrize("att,name", [(SMA, "sma_small_train"), (LSA, "lsa_small_train"), (FA2, "fa2_small_train"), (GMM, "gmm_small_train")])
+@pytest.mark.parametrize("att,name", [(SMA, "sma_small_train"), (LSA, "lsa_small_train"), (FA2, "fa2_small_train"), (GMM, "gmm_small_train"), (DCA, "dca_small_train")])
 def test_forward_backward_train(golden_dir, att, name):
     g = _load(golden_dir, name)
     B, Tin, Tsub, T, _ = (int(v) for v in g["meta"])
