@@ -30,6 +30,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+ATTENTION_NAMES = {"sma": "StepwiseMonotonicAttention", "lsa": "LSA", "fa2": "ForwardAttentionV2", "gmm": "GMMAttention",
+                   "dca": "DynamicConvolutionAttention"}
+
 # peaks from /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
@@ -121,8 +124,7 @@ def side_workload(a, rank, world, local):
     from tacotron2_subword_amd import train as T
     L.set_precision(a.dtype)
     hp = create_hparams()
-    if a.attention == "lsa":
-        hp.attention = "LSA"
+    hp.attention = ATTENTION_NAMES[a.attention]
     hp.distributed_run = False
     if world > 1:
         import torch.distributed as dist
@@ -191,8 +193,9 @@ def main():
     ap.add_argument("--tsub", type=int, default=60)
     ap.add_argument("--frames", type=int, default=0, help="frames per item (default 400; infer: decoder steps per call, default 1000)")
     ap.add_argument("--workload", choices=["train", "infer", "gta"], default="train")
-    ap.add_argument("--attention", choices=["sma", "lsa"], default="sma",
-                    help="sma = the reference's default hparams (StepwiseMonotonicAttention); lsa = LocationSensitiveAttention")
+    ap.add_argument("--attention", choices=["sma", "lsa", "fa2", "gmm", "dca"], default="sma",
+                    help="sma = the reference's default hparams (StepwiseMonotonicAttention); lsa = LocationSensitiveAttention; "
+                         "fa2 / gmm / dca = ForwardAttentionV2 / GMMAttention / DynamicConvolutionAttention")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16",
                     help="GEMM operand type: f32 = exact fp32 (parity path); bf16 = bf16 operands, fp32 accumulate/state")
@@ -216,8 +219,7 @@ def main():
 
     L.set_precision(a.dtype)
     hp = create_hparams()
-    if a.attention == "lsa":
-        hp.attention = "LSA"
+    hp.attention = ATTENTION_NAMES[a.attention]
     hp.distributed_run = world > 1
     if world > 1:
         import torch.distributed as dist
@@ -303,7 +305,7 @@ def main():
         "metric": "mel_frames_per_sec_train", "value": round(frames / dt, 1), "unit": "mel-frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": f"BERT_Tacotron2 default hparams ({'SMA' if a.attention == 'sma' else 'LSA'}), full training iteration fwd+loss+bwd+clip+Adam, "
+        "config": {"workload": f"BERT_Tacotron2 default hparams ({a.attention.upper()}), full training iteration fwd+loss+bwd+clip+Adam, "
                                f"B={B}/GPU, {Tin} phones, {Tsub} sub-word tokens, {Tn} frames, 80-mel",
                    "global_batch": world * B, "frames_per_item": Tn, "parallelism": f"dp{world}",
                    "hip_kernels": "embeddings, encoder conv/BN + BiLSTM, converters, decoder (prenets, attention LSTMs, SMA, "

@@ -203,3 +203,51 @@ def test_teacher_forced_edge_shapes(env, att, case):
     assert maxabs(dp.gate.cpu(), gate) < TOL
     assert maxabs(dp.align.cpu(), al) < TOL
     assert maxabs(dp.align_sub.cpu(), alb) < TOL
+
+
+@pytest.mark.parametrize("att", [SMA, LSA])
+def test_full_size_properties(env, att):
+    """BASELINE-sized pass (B=64, 100/60 positions, 400 frames, default dims) checked through size-independent
+    properties, since the oracle cannot run this size in seconds: every item's outputs and memory gradients equal
+    those of the same item run alone (items are independent: no cross-item arithmetic in the decoder), permuting the
+    batch permutes the outputs, alignment rows are probability-like."""
+    L, ops = env
+    hp = hp_for(att)
+    B, Tin, Tsub, T = 64, 100, 60, 400
+    P = to_dev(recipe.make_weights(hp, seed=9))
+    dims = L.dims_from_hparams(hp)
+    W = L.decoder_weights(P, dims.attention_kind)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    mem = torch.randn(B, Tin, 512, device="cuda", generator=g) * 0.5
+    mems = torch.randn(B, Tsub, 512, device="cuda", generator=g) * 0.5
+    mels = torch.randn(B, 80, T, device="cuda", generator=g)
+    tl = torch.randint(70, Tin + 1, (B,), device="cuda", generator=g); tl[0] = Tin
+    bl = torch.randint(40, Tsub + 1, (B,), device="cuda", generator=g); bl[0] = Tsub
+    dmel = torch.randn(B, T, 80, device="cuda", generator=g)
+    dgate = torch.randn(B, T, device="cuda", generator=g)
+
+    def run(idx):
+        sel = lambda t: t[idx].contiguous()
+        dp = ops.decoder_forward(W, dims, sel(mem), sel(mems), sel(tl), sel(bl), sel(mels), training=False, prenet_dropout=False, seed=0)
+        G, dm, dms = ops.decoder_backward(W, P, dims, dp, sel(mem), sel(mems), sel(dmel), sel(dgate), training=False, prenet_dropout=False, seed=0)
+        torch.cuda.synchronize()
+        return dp.mel.clone(), dp.gate.clone(), dp.align.clone(), dp.align_sub.clone(), dm.clone(), dms.clone()
+
+    full = run(torch.arange(B, device="cuda"))
+    assert all(bool(torch.isfinite(t).all()) for t in full)
+    al, als = full[2], full[3]
+    assert float(al.min()) >= 0.0 and float(als.min()) >= 0.0
+    rows, rows_s = al.sum(-1), als.sum(-1)
+    if att == LSA:
+        assert float((rows - 1).abs().max()) < 1e-4 and float((rows_s - 1).abs().max()) < 1e-4      # softmax rows
+    else:
+        assert float(rows.max()) < 1 + 1e-4 and float(rows_s.max()) < 1 + 1e-4                        # SMA mass only leaks past the end
+    for b_idx in (0, 37):                               # an item alone (MT = 1 tile) vs inside the batch of 64 (MT = 2)
+        alone = run(torch.tensor([b_idx], device="cuda"))
+        for a, f in zip(alone, full):
+            ref = f[b_idx:b_idx + 1]
+            assert float((a - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    perm = torch.randperm(B, device="cuda", generator=g)
+    shuffled = run(perm)
+    for s, f in zip(shuffled, full):
+        assert float((s - f[perm]).abs().max()) <= 1e-5 * max(1.0, float(f.abs().max()))
