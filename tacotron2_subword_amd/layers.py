@@ -27,3 +27,12 @@ class ConvNorm(nn.Module):
 
     def forward(self, signal):
         return self.conv(signal)
+
+
+def __getattr__(name):
+    """`from layers import TacotronSTFT` (layers.py:42-80 of the reference): defined in stft.py here; resolved lazily so
+    that importing the model does not pull in scipy.signal."""
+    if name == "TacotronSTFT":
+        from .stft import TacotronSTFT
+        return TacotronSTFT
+    raise AttributeError(name)
