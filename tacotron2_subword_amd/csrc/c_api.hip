@@ -224,9 +224,9 @@ int prenet(const Dec& c, bool sub, const float* X, long ldx, int M, float* P1, f
     return gemm(h, c.s);
 }
 
-// bf16-operand recurrent steps: precision mode 1, B <= 64, recurrent widths multiples of 256
+// bf16-operand recurrent steps: precision mode 1, B <= 128, recurrent widths multiples of 256
 bool use_bf16_steps(const t2_dims& d, const Sizes& z) {
-    return get_precision() == 1 && z.B <= 64 && (z.Ha + z.E) % 256 == 0 && z.Hd % 256 == 0 && (4 * z.Ha) % 2048 == 0 && (4 * z.Hd) % 2048 == 0;
+    return get_precision() == 1 && z.B <= 128 && (z.Ha + z.E) % 256 == 0 && z.Hd % 256 == 0 && (4 * z.Ha) % 2048 == 0 && (4 * z.Hd) % 2048 == 0;
 }
 // weight shadows for one pass: [W_hh | W_ih[:,P:]] (K-contiguous, forward) and its transpose laid out
 // [ctx columns | h columns] x 4H (backward), per attention stream; W_hh and W_hh^T of the decoder LSTM
@@ -897,7 +897,7 @@ int t2_decoder_infer(const t2_dims* dims_in, const t2_decoder_weights* w, const 
     for (int s = 0; s < z.NS; ++s)                                   // W1 [P,M] -> [M,P]: coalesced thread-per-output reads
         T2_TRY(permute_rows(s ? w->prenet_sub_w1 : w->prenet_w1, c.P(L.w1t) + (size_t)s * z.M * z.P, z.P, z.M, 1, c.s));
     c.I = infer_shadows(z, L.w16a);
-    c.use16 = get_precision() == 1 && z.B <= 64 && c.I.Ka % 256 == 0 && c.I.Kd % 256 == 0;
+    c.use16 = get_precision() == 1 && z.B <= 128 && c.I.Ka % 256 == 0 && c.I.Kd % 256 == 0;
     if (c.use16) {
         const long ldi = z.P + z.E;
         for (int s = 0; s < z.NS; ++s) {

@@ -766,7 +766,7 @@ int lstm_step_fwd(const LstmStepDesc& d, hipStream_t s) {
         for (int i = 0; i < d.nstreams; ++i)
             T2_REQUIRE(d.st[i].x16 && d.st[i].w16 && d.st[i].k16 % 256 == 0 && d.st[i].ldx16 % 8 == 0 && d.st[i].ldw16 % 8 == 0 &&
                        ((uintptr_t)d.st[i].x16 & 15) == 0 && ((uintptr_t)d.st[i].w16 & 15) == 0, "lstm_step: bad bf16 operands");
-        T2_REQUIRE(MT <= 2, "lstm_step: the bf16-operand step supports B <= 64");
+        T2_REQUIRE(MT <= 4, "lstm_step: the bf16-operand step supports B <= 128");
         const bool wide = d.st[0].k16 % 512 == 0 && (d.nstreams < 2 || d.st[1].k16 % 512 == 0);
         auto go = [&](auto kernel, size_t smem) -> int {
             T2_TRY_RC(allow_big_lds(kernel, smem));
@@ -776,9 +776,11 @@ int lstm_step_fwd(const LstmStepDesc& d, hipStream_t s) {
         if (MT <= 1) {
             if (wide) T2_TRY_RC(go(lstm_step_fwd_bf16_kernel<1, 512>, (size_t)(Tile16<1, 512>::SMEM_FLOATS + 32 * HU) * 4));
             else T2_TRY_RC(go(lstm_step_fwd_bf16_kernel<1, 256>, (size_t)(Tile16<1, 256>::SMEM_FLOATS + 32 * HU) * 4));
-        } else {
+        } else if (MT <= 2) {
             if (wide) T2_TRY_RC(go(lstm_step_fwd_bf16_kernel<2, 512>, (size_t)(Tile16<2, 512>::SMEM_FLOATS + 64 * HU) * 4));
             else T2_TRY_RC(go(lstm_step_fwd_bf16_kernel<2, 256>, (size_t)(Tile16<2, 256>::SMEM_FLOATS + 64 * HU) * 4));
+        } else {                                         // 65..128 rows: 256-wide stages keep the A tile within LDS
+            T2_TRY_RC(go(lstm_step_fwd_bf16_kernel<4, 256>, (size_t)(Tile16<4, 256>::SMEM_FLOATS + 128 * HU) * 4));
         }
         T2_LAUNCH_CHECK();
         return 0;
@@ -834,13 +836,19 @@ int lstm_bwd_gemm(const LstmBwdGemmDesc& d, hipStream_t s) {
     const int MT = (d.B + 31) / 32;
     dim3 grid(d.NC / 32, d.KS, d.nstreams), block(NTH);
     if (d.st[0].dg16) {
-        T2_REQUIRE(MT <= 2 && (d.H4 / d.KS) % 256 == 0, "lstm_bwd_gemm: bf16 variant needs B <= 64 and K-split spans of 256");
+        T2_REQUIRE(MT <= 4 && (d.H4 / d.KS) % 256 == 0, "lstm_bwd_gemm: bf16 variant needs B <= 128 and K-split spans of 256");
         if (MT <= 1) {
             const size_t smem = (size_t)Tile16<1, 256>::SMEM_FLOATS * 4;
+            T2_TRY_RC(allow_big_lds(lstm_bwd_gemm_bf16_kernel<1>, smem));
             hipLaunchKernelGGL(lstm_bwd_gemm_bf16_kernel<1>, grid, block, smem, s, d);
-        } else {
+        } else if (MT <= 2) {
             const size_t smem = (size_t)Tile16<2, 256>::SMEM_FLOATS * 4;
+            T2_TRY_RC(allow_big_lds(lstm_bwd_gemm_bf16_kernel<2>, smem));
             hipLaunchKernelGGL(lstm_bwd_gemm_bf16_kernel<2>, grid, block, smem, s, d);
+        } else {
+            const size_t smem = (size_t)Tile16<4, 256>::SMEM_FLOATS * 4;
+            T2_TRY_RC(allow_big_lds(lstm_bwd_gemm_bf16_kernel<4>, smem));
+            hipLaunchKernelGGL(lstm_bwd_gemm_bf16_kernel<4>, grid, block, smem, s, d);
         }
         T2_LAUNCH_CHECK();
         return 0;

@@ -289,3 +289,36 @@ def test_alignment_guide_loss_gradients_reach_the_decoder(mode):
         if not err < 1e-3:
             bad[k] = err
     assert not bad, bad
+
+
+def test_bf16_steps_at_batch_96_track_fp32():
+    """B in (64, 128]: the bf16-operand recurrent steps use four 32-row tiles per workgroup; outputs and memory
+    gradients stay close to the fp32 path (same bound style as the B <= 64 closeness tests)."""
+    from tacotron2_subword_amd import _lib as L
+    from tacotron2_subword_amd import ops
+    from helpers import to_dev
+    hp = hp_for(SMA)
+    B, Tin, Tsub, T = 96, 24, 17, 20
+    P = to_dev(recipe.make_weights(hp, seed=2))
+    dims = L.dims_from_hparams(hp)
+    W = L.decoder_weights(P, dims.attention_kind)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    mem = torch.randn(B, Tin, 512, device="cuda", generator=g) * 0.5
+    mems = torch.randn(B, Tsub, 512, device="cuda", generator=g) * 0.5
+    mels = torch.randn(B, 80, T, device="cuda", generator=g)
+    tl = torch.full((B,), Tin, device="cuda"); bl = torch.full((B,), Tsub, device="cuda")
+    dmel = torch.randn(B, T, 80, device="cuda", generator=g); dgate = torch.randn(B, T, device="cuda", generator=g)
+    res = {}
+    for mode in ("f32", "bf16"):
+        L.set_precision(mode)
+        try:
+            dp = ops.decoder_forward(W, dims, mem, mems, tl, bl, mels, training=False, prenet_dropout=False, seed=0)
+            G, dm, dms = ops.decoder_backward(W, P, dims, dp, mem, mems, dmel, dgate, training=False, prenet_dropout=False, seed=0)
+            torch.cuda.synchronize()
+            res[mode] = (dp.mel.clone(), dp.gate.clone(), dp.align.clone(), dm.clone(), G["decoder.decoder_rnn.weight_hh"].clone())
+        finally:
+            L.set_precision("f32")
+    a, b = res["f32"], res["bf16"]
+    assert maxabs(a[0], b[0]) < 0.05 and maxabs(a[1], b[1]) < 0.05 and maxabs(a[2], b[2]) < 0.02
+    for x, y in zip(a[3:], b[3:]):
+        assert float((x - y).norm() / x.norm()) < 0.15
