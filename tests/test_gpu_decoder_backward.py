@@ -154,3 +154,56 @@ def test_two_stream_schedule_is_bitwise_identical(env):
             assert torch.equal(a, b)
         for k in res[0][4]:
             assert torch.equal(res[0][4][k], other[4][k]), k
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_shapes_forward_and_backward(env, seed):
+    """Seeded random sweep over batch / memory / frame counts and attention kinds (tiny dims): forward within 1e-4 of
+    the oracle, gradients within the rule above.  Shapes deliberately avoid multiples of the tile sizes."""
+    L, ops = env
+    rs = np.random.RandomState(1000 + seed)
+    att = [SMA, LSA, FA2, GMM, DCA][seed % 5]
+    B, Tin, Tsub, T = int(rs.randint(1, 71)), int(rs.randint(1, 91)), int(rs.randint(1, 51)), int(rs.randint(1, 46))
+    hp = tiny_hp(att)
+    P = recipe.make_weights(hp, seed=40 + seed)
+    x, y = recipe.parse_batch(recipe.make_batch(hp, B, Tin, Tsub, T, seed=seed))
+    mem, mem_sub = oracle_memories(P, hp, x)
+    kind = {SMA: L.ATTN_SMA, GMM: L.ATTN_GMM, DCA: L.ATTN_DCA}.get(att, L.ATTN_LSA)
+    dec_keys = ["decoder." + k for k in L.decoder_param_keys(kind)]
+    g = torch.Generator().manual_seed(seed)
+    R_mel, R_gate = torch.randn(B, hp["n_mel_channels"], T, generator=g), torch.randn(B, T, generator=g)
+    R_al = torch.randn(B, T, Tin, generator=g)
+
+    def autograd(dt):
+        cv = lambda v: v.to(dt) if torch.is_tensor(v) and v.is_floating_point() else v
+        Pg = {k: (cv(v).clone().requires_grad_(True) if k in dec_keys else cv(v)) for k, v in P.items()}
+        m1, m2 = cv(mem).clone().requires_grad_(True), cv(mem_sub).clone().requires_grad_(True)
+        mel, gate, al, alb = O.decoder_forward(m1, m2, cv(x[3]), x[1], x[2], Pg, hp, None)
+        ((mel * cv(R_mel)).sum() + (gate * cv(R_gate)).sum() + (al * cv(R_al)).sum()).backward()
+        out = {k: Pg[k].grad for k in dec_keys}
+        out["d_memory"], out["d_memory_sub"] = m1.grad, m2.grad
+        return (mel.detach(), gate.detach(), al.detach(), alb.detach()), out
+
+    fwd32, g32 = autograd(torch.float32)
+    _, g64 = autograd(torch.float64)
+    dims = L.dims_from_hparams(hp)
+    Pd = to_dev(P)
+    W = L.decoder_weights(Pd, dims.attention_kind)
+    memd, memsd = mem.cuda().contiguous(), mem_sub.cuda().contiguous()
+    dp = ops.decoder_forward(W, dims, memd, memsd, x[1].cuda(), x[2].cuda(), x[3].cuda().contiguous(), training=False, prenet_dropout=False, seed=0)
+    for got, ref in zip((dp.mel.transpose(1, 2), dp.gate, dp.align, dp.align_sub), fwd32):
+        assert maxabs(got, ref) < 1e-4, (att, B, Tin, Tsub, T)
+    G, dmem, dmems = ops.decoder_backward(W, Pd, dims, dp, memd, memsd, R_mel.transpose(1, 2).contiguous().cuda(), R_gate.cuda().contiguous(),
+                                          training=False, prenet_dropout=False, seed=0, d_align=R_al.cuda().contiguous())
+    torch.cuda.synchronize()
+    G = dict(G)
+    G["d_memory"], G["d_memory_sub"] = dmem, dmems
+    rel = lambda a, ref: maxabs(a.double(), ref.double()) / max(float(ref.abs().max()), 1e-6)
+    att_noise = max(rel(g32[k], g64[k]) for k in g64 if "attention_layer" in k)
+    bad = {}
+    for k, ref in g64.items():
+        noise = att_noise if "attention_layer" in k else rel(g32[k], ref)
+        err, tol = rel(G[k], ref), max(RTOL, 3.0 * noise)
+        if not err < tol:
+            bad[k] = (err, tol)
+    assert not bad, (att, B, Tin, Tsub, T, bad)
