@@ -182,9 +182,11 @@ int t2_decoder_backward(const t2_dims* dims, const t2_decoder_weights* w, const 
 
 /* Autoregressive decode — replaces Decoder.inference (model.py:430-492) for any B.
  * Per-item stop rule: stop_index[b] = first t with sigmoid(gate) > threshold.
- * Runs until every item has stopped or max_steps; the host polls a device counter every
- * `poll_every` steps (the only synchronisation).  Returns the number of steps run in
- * *steps_run_host; frames after an item's stop are computed-but-meaningless. */
+ * Runs until every item has stopped or max_steps.  Every `poll_every` steps a device counter is copied to pinned
+ * memory behind an event and the host reads the copy made two polls earlier, so it only blocks when it is more than
+ * 2*poll_every steps ahead of the GPU (the queue never drains); the loop therefore runs up to 3*poll_every steps past
+ * the last stop.  Returns the number of steps run in *steps_run_host; frames after an item's stop index are
+ * computed-but-meaningless. */
 typedef struct t2_decoder_infer_args {
     int B, Tin, Tsub, max_steps, poll_every;
     float gate_threshold;

@@ -92,6 +92,21 @@ static int stream_edge(Side& sd, size_t i, hipStream_t from, hipStream_t to) {
     return 0;
 }
 
+// Pinned slots + events of the decode loop's stop polling (one set per device)
+struct StopPoll { hipEvent_t ev[4] = {}; int32_t* host = nullptr; };
+static StopPoll g_poll[16];
+static int stop_poll_get(StopPoll** out) {
+    int dev = 0;
+    T2_CHECK_HIP(hipGetDevice(&dev));
+    StopPoll& p = g_poll[dev & 15];
+    if (!p.host) {
+        T2_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&p.host), 4 * sizeof(int32_t), hipHostMallocDefault));
+        for (auto& e : p.ev) T2_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    *out = &p;
+    return 0;
+}
+
 namespace {
 
 struct Sizes {
@@ -938,6 +953,8 @@ int t2_decoder_infer(const t2_dims* dims_in, const t2_decoder_weights* w, const 
         return step_tail(d, c.s);
     };
     int steps = 0;
+    StopPoll* pl = nullptr;
+    T2_TRY(stop_poll_get(&pl));
     T2_TRY(tail(0, false));                                          // prenet of the go frame (model.py:444-450)
     for (int t = 0; t < T; ++t) {
         T2_TRY(att_lstm_step(c, t));
@@ -945,11 +962,19 @@ int t2_decoder_infer(const t2_dims* dims_in, const t2_decoder_weights* w, const 
         T2_TRY(dec_lstm_step(c, t));
         T2_TRY(tail(t, true));                                       // mel_t, gate_t, stop rule, prenets of step t+1 (:470-471)
         steps = t + 1;
-        if (steps % poll == 0 || steps == T) {
-            int32_t done = 0;
-            T2_CHECK_HIP(hipMemcpyAsync(&done, a->done_count, sizeof(done), hipMemcpyDeviceToHost, c.s));
-            T2_CHECK_HIP(hipStreamSynchronize(c.s));
-            if (done >= z.B) break;
+        if (steps % poll == 0 && steps < T) {
+            // Stop rule without draining the queue: the counter is copied to pinned memory behind an event; the host reads
+            // the copy made TWO polls ago, so it blocks only when it is more than 2*poll steps ahead of the GPU and the
+            // GPU always has work queued.  The loop overshoots the last stop by at most 3*poll steps (their frames are
+            // past every item's stop index).
+            const int k = steps / poll, slot = k & 3;
+            T2_CHECK_HIP(hipMemcpyAsync(pl->host + slot, a->done_count, sizeof(int32_t), hipMemcpyDeviceToHost, c.s));
+            T2_CHECK_HIP(hipEventRecord(pl->ev[slot], c.s));
+            if (k >= 3) {
+                const int prev = (k - 2) & 3;
+                T2_CHECK_HIP(hipEventSynchronize(pl->ev[prev]));
+                if (pl->host[prev] >= z.B) break;
+            }
         }
     }
     *a->steps_run_host = steps;

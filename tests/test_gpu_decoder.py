@@ -140,7 +140,7 @@ def test_inference_vs_golden(env, att, name):
     torch.cuda.synchronize()
     k = int(g["stop_index"])
     assert int(stop2[0]) == k
-    assert k + 1 <= n2 <= k + 4
+    assert k + 1 <= n2 <= k + 1 + 3 * 4                  # the loop may run up to 3 polls past the stop (t2amd.h)
     assert maxabs(dp2.mel[:, :k + 1].cpu().transpose(1, 2), g["stop_mel"]) < TOL
 
 
