@@ -366,6 +366,69 @@ __device__ __forceinline__ void store16_mc(__bf16* __restrict__ lds, const bf16x
     for (int mm = 0; mm < 4; ++mm) *reinterpret_cast<bf16x8*>(lds + swz16(row + mm, ks)) = regs[mm];
 }
 
+// ---- two-phase loaders of an INTERIOR tile (all 128 rows and all 64 k in range, 16-byte aligned): `issue` only requests
+// the fp32 data into registers, `finish` converts and stores to LDS.  Keeping the raw registers alive lets the main loop
+// hold TWO k-steps in flight per wave: measured on the old loop the wait + convert sat directly behind the loads, in
+// front of the MFMAs (one k-step of 64 KB in flight per workgroup = the ~50 GB/s per CU that bounded the kernel).
+struct RawKC { f32x4 lo[4], hi[4]; unsigned ok; };
+struct RawMC { f32x4 v[8]; unsigned ok; };
+__device__ __forceinline__ void issue_kc(const float* __restrict__ base, long srow, int row0, int k0, ConvAddr cv, RawKC& r) {
+    r.ok = 0xFu;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = threadIdx.x + i * 256, row = row0 + (q >> 3), k = k0 + (q & 7) * 8;
+        const float* p;
+        if (cv.T) {
+            const int dk = k / cv.C, ci = k - dk * cv.C, t = row % cv.T + dk - cv.pad;
+            const bool ok = t >= 0 && t < cv.T;
+            if (!ok) r.ok &= ~(1u << i);
+            p = base + (ok ? (long)(row + dk - cv.pad) * cv.C + ci : 0l);
+        } else {
+            p = base + (long)row * srow + k;
+        }
+        r.lo[i] = *reinterpret_cast<const f32x4*>(p); r.hi[i] = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+}
+__device__ __forceinline__ void finish_kc(__bf16* __restrict__ lds, const RawKC& r) {
+    const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = threadIdx.x + i * 256;
+        const bool ok = (r.ok >> i) & 1u;
+        *reinterpret_cast<bf16x8*>(lds + swz16(q >> 3, q & 7)) = pack8(ok ? r.lo[i] : zz, ok ? r.hi[i] : zz);
+    }
+}
+__device__ __forceinline__ void issue_mc(const float* __restrict__ base, long sk, int row0, int k0, ConvAddr cv, RawMC& r) {
+    const int row = row0 + (threadIdx.x & 31) * 4, kb = k0 + (threadIdx.x >> 5) * 8;
+    r.ok = 0xFFu;
+    if (cv.T) {
+        const int dk = row / cv.C, ci = row - dk * cv.C;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int k = kb + kk, t = k % cv.T + dk - cv.pad;
+            const bool ok = t >= 0 && t < cv.T;
+            if (!ok) r.ok &= ~(1u << kk);
+            r.v[kk] = *reinterpret_cast<const f32x4*>(base + (ok ? (long)(k + dk - cv.pad) * cv.C + ci : 0l));
+        }
+    } else {
+        const float* p = base + (long)kb * sk + row;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) r.v[kk] = *reinterpret_cast<const f32x4*>(p + (long)kk * sk);
+    }
+}
+__device__ __forceinline__ void finish_mc(__bf16* __restrict__ lds, const RawMC& r) {
+    const int row = (threadIdx.x & 31) * 4, ks = threadIdx.x >> 5;
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm) {
+        bf16x8 o;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) o[kk] = (__bf16)(((r.ok >> kk) & 1u) ? r.v[kk][mm] : 0.f);
+        *reinterpret_cast<bf16x8*>(lds + swz16(row + mm, ks)) = o;
+    }
+}
+template <bool KC> struct RawOf { using type = RawMC; };
+template <> struct RawOf<true> { using type = RawKC; };
+
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmK g) {
     const GemmDesc& d = g.d;
@@ -394,6 +457,52 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmK g) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const ConvAddr cva{d.conv_a ? d.conv_T : 0, d.conv_C, d.conv_pad}, cvb{d.conv_b ? d.conv_T : 0, d.conv_C, d.conv_pad};
+    // interior workgroup: every tile row/column in range, whole 64-wide k-steps, aligned operands -> pipelined loop
+    const bool interior = m0 + 128 <= d.M && n0 + 128 <= d.N && kbeg < kend && (kend - kbeg) % BK16 == 0 && g.avec && g.bvec;
+    if (interior) {
+        using RA = typename RawOf<A_KC>::type;
+        using RB = typename RawOf<B_KC>::type;
+        RA a0; RB b0;
+        auto issue = [&](int k0, RA& ra_, RB& rb_) {
+            if constexpr (A_KC) issue_kc(A, d.sam, m0, k0, cva, ra_); else issue_mc(A, d.sak, m0, k0, cva, ra_);
+            if constexpr (B_KC) issue_kc(B, d.sbn, n0, k0, cvb, rb_); else issue_mc(B, d.sbk, n0, k0, cvb, rb_);
+        };
+        auto finish = [&](int buf, const RA& ra_, const RB& rb_) {
+            if constexpr (A_KC) finish_kc(As(buf), ra_); else finish_mc(As(buf), ra_);
+            if constexpr (B_KC) finish_kc(Bs(buf), rb_); else finish_mc(Bs(buf), rb_);
+        };
+        auto mma = [&](int buf) {
+            const __bf16* as = As(buf);
+            const __bf16* bs = Bs(buf);
+#pragma unroll
+            for (int ks = 0; ks < BK16 / 16; ++ks) {
+                bf16x8 a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(as + swz16(wm * 64 + i * 32 + r, 2 * ks + h));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bs + swz16(wn * 64 + j * 32 + r, 2 * ks + h));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        };
+        const int nks = (kend - kbeg) / BK16;
+        issue(kbeg, a0, b0);
+        finish(0, a0, b0);
+        __syncthreads();
+        int cur = 0;
+        for (int ks = 0; ks < nks; ++ks) {
+            const bool more = ks + 1 < nks;
+            if (more) issue(kbeg + (ks + 1) * BK16, a0, b0);          // in flight during the MFMAs below
+            __builtin_amdgcn_sched_barrier(0);
+            mma(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) finish(cur ^ 1, a0, b0);
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
     bf16x8 ra[4], rb[4];
     auto load = [&](int k0) {
         if (A_KC) load16_kc(A, d.sam, m0, d.M, k0, kend, g.avec, cva, ra); else load16_mc(A, d.sak, m0, d.M, k0, kend, g.avec, cva, ra);
@@ -426,6 +535,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmK g) {
         if (more) store(cur ^ 1);
         __syncthreads();
         cur ^= 1;
+    }
     }
 
     const RngKey key = rng_key(d.seed, d.site);
