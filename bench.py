@@ -309,8 +309,8 @@ def main():
                                f"B={B}/GPU, {Tin} phones, {Tsub} sub-word tokens, {Tn} frames, 80-mel",
                    "global_batch": world * B, "frames_per_item": Tn, "parallelism": f"dp{world}",
                    "hip_kernels": "embeddings, encoder conv/BN + BiLSTM, converters, decoder (prenets, attention LSTMs, SMA, "
-                                  "decoder LSTM, projections), postnet conv/BN: forward and backward",
-                   "torch_ops": "loss reductions, clip_grad_norm_, Adam, cat/transpose copies",
+                                  "decoder LSTM, projections), postnet conv/BN: forward and backward; gradient-norm clip + Adam",
+                   "torch_ops": "loss reductions, cat/transpose copies",
                    "precision": ("bf16 operands / fp32 accumulate for every GEMM (hoisted LSTM input halves, per-step recurrent "
                                  "LSTM GEMMs via bf16 weight/activation shadows, convolutions, projections, weight gradients); "
                                  "LSTM gates/state, BatchNorm statistics, attention energies/recurrences, master weights, "

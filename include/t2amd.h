@@ -285,6 +285,17 @@ int t2_gemm_ex(const t2_gemm_args* a, void* stream);
 int t2_colsum(const float* x, long ld, int M, int N, float* out, float* scratch, void* stream);
 int t2_mask_btc(float* x, int B, int T, int C, const int32_t* lengths, float fill, void* stream);
 
+/* Gradient-norm clipping + Adam over a list of fp32 tensors — replaces torch.nn.utils.clip_grad_norm_ +
+ * torch.optim.Adam.step of the training loop (train.py:322-330; Adam with weight decay added to the gradient).
+ * `table` is a DEVICE array of n_tensors rows; row i covers chunks [first_chunk, first_chunk + t2_adam_chunks(numel))
+ * and the rows are sorted by first_chunk (consecutive).  partial: n_chunks floats of scratch; norm_out: 2 floats
+ * (total gradient norm, clip coefficient applied).  max_norm <= 0 disables clipping.  step counts from 1.
+ * Gradients are read, not modified (the coefficient is applied on the fly). */
+typedef struct t2_adam_tensor { float* p; const float* g; float* m; float* v; long numel; int first_chunk; int pad_; } t2_adam_tensor;
+int t2_adam_chunks(long numel);
+int t2_adam_step(const t2_adam_tensor* table, int n_tensors, int n_chunks, float* partial, float* norm_out, float max_norm,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+
 /* In-situ kernel timing for bench.py's roofline figures: after t2_prof_enable(n) the decoder
  * drivers bracket each per-step kernel launch with HIP events on the launch stream (up to n
  * launches); t2_prof_collect synchronises on the last event and returns total milliseconds and

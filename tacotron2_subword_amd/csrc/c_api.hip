@@ -1142,6 +1142,14 @@ int t2_prof_collect(int n_kinds, double* total_ms_host, int* launches_host) {
     return 0;
 }
 
+int t2_adam_chunks(long numel) { return adam_chunks(numel); }
+int t2_adam_step(const t2_adam_tensor* table, int n_tensors, int n_chunks, float* partial, float* norm_out, float max_norm,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+    static_assert(sizeof(t2_adam_tensor) == sizeof(AdamTensor), "table row layout");
+    return adam_step(reinterpret_cast<const AdamTensor*>(table), n_tensors, n_chunks, partial, norm_out, max_norm, lr, beta1, beta2, eps,
+                     weight_decay, step, (hipStream_t)stream);
+}
+
 int t2_finalize_bct(const float* in_btc, float* out_bct, int B, int T, int C, const int32_t* lengths, float fill, void* stream) {
     return transpose_btc_to_bct(in_btc, out_bct, B, T, C, lengths, fill, (hipStream_t)stream);
 }

@@ -222,6 +222,12 @@ int conv_bn_bwd(const ConvBnBwd& a, hipStream_t s);
 int embedding_fwd(const long* ids, const float* table, float* out, int rows, int D, hipStream_t s);
 int embedding_bwd(const long* ids, const float* dout, float* dtable, int rows, int D, int vocab, hipStream_t s);
 
+// ------------------------------------------------------------------ optimizer (optim.hip)
+struct AdamTensor { float* p; const float* g; float* m; float* v; long numel; int first_chunk; int pad_; };   // 48 bytes, mirrors t2_adam_tensor
+int adam_chunks(long numel);
+int adam_step(const AdamTensor* table_dev, int n_tensors, int n_chunks, float* partial, float* norm_out, float max_norm,
+              float lr, float b1, float b2, float eps, float wd, int step, hipStream_t s);
+
 // ------------------------------------------------------------------ elementwise (elementwise.hip)
 int rng_keep_mask(uint64_t seed, uint32_t site, uint32_t n, float p, uint8_t* out, hipStream_t s);
 int rng_normal(uint64_t seed, uint32_t site, uint32_t n, float* out, hipStream_t s);

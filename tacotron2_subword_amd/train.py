@@ -17,6 +17,7 @@ import torch.distributed as dist
 from .distributed import apply_gradient_allreduce
 from .loss_function import Tacotron2Loss
 from .model import BERT_Tacotron2
+from .optim import FusedAdam
 
 
 def reduce_tensor(tensor, n_gpus):
@@ -122,8 +123,11 @@ def train_step(model, criterion, optimizer, x, y, hparams, iteration=0):
     y_pred = model(x)
     loss, mel_loss, gate_loss, _, _ = criterion(y_pred, y, x, iteration)
     loss.backward()
-    torch.nn.utils.clip_grad_norm_(model.parameters(), hparams.grad_clip_thresh)
-    optimizer.step()
+    if hasattr(optimizer, "last_norm"):                        # optim.FusedAdam: clip + Adam in two HIP passes
+        optimizer.step(max_norm=hparams.grad_clip_thresh)
+    else:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), hparams.grad_clip_thresh)
+        optimizer.step()
     return loss
 
 
@@ -132,6 +136,7 @@ def make_training_objects(hparams):
     torch.manual_seed(hparams.seed)
     torch.cuda.manual_seed(hparams.seed)
     model = load_model(hparams)
-    optimizer = torch.optim.Adam(model.parameters(), lr=hparams.learning_rate, weight_decay=hparams.weight_decay)
+    # train.py:210-211 builds torch.optim.Adam(lr, weight_decay); FusedAdam is that optimizer with a HIP step()
+    optimizer = FusedAdam(model.parameters(), lr=hparams.learning_rate, weight_decay=hparams.weight_decay)
     criterion = Tacotron2Loss(hparams.alignloss)
     return model, optimizer, criterion

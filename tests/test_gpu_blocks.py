@@ -127,3 +127,32 @@ def test_bilstm_vs_oracle(env, packed):
     assert rel(xd.grad, x.grad) < 3e-4
     for (k, p), (_, q) in zip(lstm.named_parameters(), dl.named_parameters()):
         assert rel(q.grad, p.grad) < 3e-4, k
+
+
+def test_fused_adam_matches_clip_plus_torch_adam():
+    """optim.FusedAdam.step(max_norm) vs torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step over odd-sized tensors,
+    several steps, with and without clipping being active; state_dicts interchange."""
+    from tacotron2_subword_amd.optim import FusedAdam
+    g = torch.Generator(device="cuda").manual_seed(0)
+    shapes = [(4096, 768), (1, 128), (8193,), (33, 7, 5), (80,), (3,)]
+    ref_p = [torch.randn(s, device="cuda", generator=g).requires_grad_(True) for s in shapes]
+    fus_p = [p.detach().clone().requires_grad_(True) for p in ref_p]
+    ref_p.append(torch.zeros(5, device="cuda", requires_grad=True)); fus_p.append(torch.zeros(5, device="cuda", requires_grad=True))   # never gets a grad
+    ref = torch.optim.Adam(ref_p, lr=1e-3, weight_decay=1e-6)
+    fus = FusedAdam(fus_p, lr=1e-3, weight_decay=1e-6)
+    for step in range(4):
+        scale = 0.01 if step == 2 else 1.0                          # step 2: norm below the threshold -> coefficient 1
+        for a, b in zip(ref_p[:-1], fus_p[:-1]):
+            grad = torch.randn(a.shape, device="cuda", generator=g) * scale
+            a.grad, b.grad = grad.clone(), grad.clone()
+        want_norm = torch.nn.utils.clip_grad_norm_(ref_p, 1.0)
+        ref.step()
+        got_norm = fus.step(max_norm=1.0)
+        assert abs(float(got_norm) - float(want_norm)) < 1e-4 * float(want_norm)
+        for a, b in zip(ref_p, fus_p):
+            assert float((a - b).abs().max()) < 2e-6, step
+    sd = fus.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 4.0
+    ref2 = torch.optim.Adam([p.detach().clone().requires_grad_(True) for p in fus_p], lr=1e-3, weight_decay=1e-6)
+    ref2.load_state_dict(sd)                                        # FusedAdam state loads into torch.optim.Adam
+    assert fus_p[-1].grad is None and len(fus.state[fus_p[-1]]) == 0
