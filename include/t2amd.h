@@ -51,6 +51,11 @@ int t2_get_precision(void);
 /* 1 (default): teacher-forced passes run the decoder-LSTM chain on an internal side stream, one chunk of steps
  * apart from the attention chain (fork/join inside the call; the caller's stream semantics are unchanged).  0: one stream. */
 int t2_set_overlap(int on);
+/* bf16 mode only.  1 (default): a large GEMM whose extents are whole 128x128x64 tiles first writes bf16 copies of its
+ * fp32 operands (K contiguous) into the caller's scratch and runs the bf16-source kernel on them (half the operand
+ * bytes per MFMA; implicit-conv operands included).  0: always convert while staging through LDS.  Same rounding
+ * of the operands either way; only the summation order inside a dot product differs. */
+int t2_set_gemm_staging(int on);
 
 /* Model dimensions (hparams.py:55-95). */
 typedef struct t2_dims {
@@ -225,7 +230,7 @@ typedef struct t2_conv_bn_args {
     const float* residual;             /* optional, added to the output (mel + postnet(mel), model.py:558) */
     float* z; float* mean; float* invstd; float* var;   /* saved: [B*T,Cout], [Cout] x3 */
     float* y;                          /* [B*T, Cout] */
-    float* ws; size_t ws_floats;       /* scratch >= Cout*Cin*K + 128*Cout floats */
+    float* ws; size_t ws_floats;       /* scratch >= Cout*Cin*K + 128*Cout floats; anything beyond is used for bf16 operand staging (bf16 mode) */
 } t2_conv_bn_args;
 int t2_conv_bn_forward(const t2_conv_bn_args* a, void* stream);
 typedef struct t2_conv_bn_bwd_args {
@@ -236,7 +241,7 @@ typedef struct t2_conv_bn_bwd_args {
     const float* dy;                   /* [B*T, Cout] */
     float* dw; float* dbias; float* dgamma; float* dbeta;
     float* dx; int dx_accumulate;      /* [B*T, Cin] or NULL */
-    float* ws; size_t ws_floats;       /* scratch >= B*T*Cout + Cout*Cin*K + 128*Cout + split-K space */
+    float* ws; size_t ws_floats;       /* scratch >= B*T*Cout + Cout*Cin*K + 128*Cout + split-K / bf16 staging space */
 } t2_conv_bn_bwd_args;
 int t2_conv_bn_backward(const t2_conv_bn_bwd_args* a, void* stream);
 

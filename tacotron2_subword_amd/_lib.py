@@ -149,7 +149,7 @@ class GemmArgs(C.Structure):
 
 
 # every symbol include/t2amd.h declares (tests/test_abi.py checks the library exports them all)
-EXPORTS = ["t2_last_error", "t2_version", "t2_set_precision", "t2_get_precision", "t2_set_overlap", "t2_decoder_layout_query", "t2_decoder_forward", "t2_decoder_infer",
+EXPORTS = ["t2_last_error", "t2_version", "t2_set_precision", "t2_get_precision", "t2_set_overlap", "t2_set_gemm_staging", "t2_decoder_layout_query", "t2_decoder_forward", "t2_decoder_infer",
            "t2_decoder_bwd_layout_query", "t2_decoder_backward", "t2_prof_enable", "t2_prof_collect", "t2_adam_chunks", "t2_adam_step",
            "t2_conv_bn_forward", "t2_conv_bn_backward", "t2_embedding_forward", "t2_embedding_backward",
            "t2_lstm_seq_forward", "t2_lstm_seq_backward", "t2_gemm_ex", "t2_colsum", "t2_mask_btc",

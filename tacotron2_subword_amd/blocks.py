@@ -130,7 +130,7 @@ class _ConvStackFn(torch.autograd.Function):
             z = torch.empty(M, Cout, dtype=torch.float32, device=dev)
             y = torch.empty(B, T, Cout, dtype=torch.float32, device=dev)
             st = torch.empty(3, Cout, dtype=torch.float32, device=dev)      # mean, invstd, var
-            nws = Cout * Cin * K + 4 + 128 * Cout
+            nws = Cout * Cin * K + 4 + 128 * Cout + (M * Cin + Cout * Cin * K) // 2 + 4096    # + bf16 operand staging + split-K
             ws = _scratch(dev, nws)
             res = x if (cfg["residual"] and i == n - 1) else None
             a = L.ConvBnArgs(B, T, Cin, Cout, K, L.ptr(cur), L.ptr(w.detach()), L.ptr(bias.detach()), L.ptr(gamma.detach()),
@@ -161,7 +161,7 @@ class _ConvStackFn(torch.autograd.Function):
             dg, dbt = torch.empty_like(gamma), torch.empty_like(beta)
             need_dx = i > 0 or ctx.needs_input_grad[0]
             dx = torch.empty(B, T, Cin, dtype=torch.float32, device=dev) if need_dx else None
-            nws = M * Cout + Cout * Cin * K + 128 * Cout + 16 + (8 << 20)
+            nws = M * Cout + Cout * Cin * K + 128 * Cout + 16 + (8 << 20) + (M * (Cout + K * max(Cin, Cout))) // 2 + Cout * Cin * K
             ws = _scratch(dev, nws)
             a = L.ConvBnBwdArgs(B, T, Cin, Cout, K, L.ptr(xin), L.ptr(w), L.ptr(gamma), L.ptr(beta), L.ptr(z), L.ptr(st[0]), L.ptr(st[1]),
                                 int(cfg["training"]), 1e-5, cfg["acts"][i], cfg["drop_p"] if cfg["training"] else 0.0, cfg["seed"],

@@ -468,7 +468,7 @@ void bwd_layout_of(const t2_dims& d, const Sizes& z, t2_decoder_bwd_layout* L) {
     L->dmel_t = take(BT * z.M); L->dgate_t = take(BT);
     L->dg16a = take((size_t)2 * z.B * 4 * z.Ha / 2 + 4); L->dg16d = take((size_t)z.B * 4 * z.Hd / 2 + 4);
     L->colsum_ws = take((size_t)64 * 4 * (z.Ha > z.Hd ? z.Ha : z.Hd));
-    L->gemm_ws_floats = (size_t)48 << 20;                     // 192 MiB of split-K scratch
+    L->gemm_ws_floats = (size_t)128 << 20;                    // 512 MiB: split-K partials + bf16 operand staging (gemm.hip)
     L->gemm_ws = take(L->gemm_ws_floats);
     L->total_floats = off;
 }
@@ -645,6 +645,7 @@ int t2_set_precision(int mode) {
 }
 int t2_get_precision(void) { return get_precision(); }
 int t2_set_overlap(int on) { g_overlap = on != 0; return 0; }
+int t2_set_gemm_staging(int on) { set_gemm_staging(on); return 0; }
 
 int t2_decoder_layout_query(const t2_dims* dims_in, int B, int T, int Tin, int Tsub, t2_decoder_layout* out) {
     T2_REQUIRE(dims_in && out, "null argument");
@@ -688,6 +689,7 @@ int t2_decoder_forward(const t2_dims* dims_in, const t2_decoder_weights* w, cons
         const t2_lstm_weights& lw = s ? w->att_sub : w->att;
         GemmDesc g = linear(c.P(s ? L.p2s : L.p2), z.P, lw.w_ih, z.P + z.E, c.P(s ? L.preas : L.prea), 4 * z.Ha, BT, 4 * z.Ha, z.P);
         g.bias1 = lw.b_ih; g.bias2 = lw.b_hh;
+        g.ws = c.P(L.gemm_ws); g.ws_bytes = L.gemm_ws_floats * sizeof(float);       // bf16 staging (gemm.hip)
         T2_TRY(gemm(g, c.s));
     }
     // Two serial chains, overlapped in chunks of steps:
@@ -699,6 +701,12 @@ int t2_decoder_forward(const t2_dims* dims_in, const t2_decoder_weights* w, cons
     if (overlap) { T2_TRY(side_get(&side)); c.sd = side->s; }
     const int CH = overlap ? std::max(16, (z.T + 7) / 8) : z.T;
     size_t ne = 0;
+    // bf16 steps keep a bf16 shadow of every DIN row (din16): with one bf16 copy of W_ih at the head of the scratch the
+    // chunk GEMMs below read both operands as bf16 and stage nothing
+    const size_t w16_bytes = ((size_t)4 * z.Hd * z.WD * sizeof(__bf16) + 255) & ~(size_t)255;
+    const bool pre16 = c.use16 && (4 * z.Hd) % 64 == 0 && z.WD % 64 == 0 && L.gemm_ws_floats * sizeof(float) > w16_bytes;
+    __bf16* w16 = reinterpret_cast<__bf16*>(c.P(L.gemm_ws));
+    if (pre16) T2_TRY(stage_bf16(w->dec.w_ih, true, z.WD, w16, 4 * z.Hd, z.WD, c.s));
     for (int t0 = 0; t0 < z.T; t0 += CH) {
         const int t1 = std::min(z.T, t0 + CH);
         for (int t = t0; t < t1; ++t) {
@@ -710,6 +718,12 @@ int t2_decoder_forward(const t2_dims* dims_in, const t2_decoder_weights* w, cons
         GemmDesc g = linear(c.P(L.din) + c.R(t0) * z.WD, z.WD, w->dec.w_ih, z.WD, c.P(L.pred) + c.R(t0) * 4 * z.Hd, 4 * z.Hd,
                             (t1 - t0) * z.B, 4 * z.Hd, z.WD);
         g.bias1 = w->dec.b_ih; g.bias2 = w->dec.b_hh;
+        g.ws = c.P(L.gemm_ws); g.ws_bytes = L.gemm_ws_floats * sizeof(float);       // chain A launches no GEMM: the scratch is chain B's
+        if (pre16) {
+            g.A16 = c.P16(L.din16) + c.R(t0) * z.WD; g.lda16 = z.WD;
+            g.B16 = w16; g.ldb16 = z.WD;
+            g.ws = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(g.ws) + w16_bytes); g.ws_bytes -= w16_bytes;
+        }
         T2_TRY(gemm(g, sb));
         for (int t = t0; t < t1; ++t) T2_TRY(dec_lstm_step(c, t));
     }
@@ -775,21 +789,45 @@ int t2_decoder_backward(const t2_dims* dims_in, const t2_decoder_weights* w, con
     }
     const int CH = overlap ? std::max(16, (z.T + 7) / 8) : z.T;
     const float* DGd = c.S(BL.dgd);
+    // bf16 mode: W_ih^T ([WD][4Hd], K contiguous) is staged once at the head of the scratch for all dDIN chunks
+    unsigned char* const ws8 = reinterpret_cast<unsigned char*>(c.gemm_ws());
+    const size_t wt_bytes = ((size_t)4 * z.Hd * z.WD * sizeof(__bf16) + 255) & ~(size_t)255;
+    const bool pre16 = get_precision() == 1 && (4 * z.Hd) % 64 == 0 && z.WD % 64 == 0 && c.gemm_ws_bytes() > 2 * wt_bytes;
+    if (pre16) T2_TRY(stage_bf16(w->dec.w_ih, false, z.WD, reinterpret_cast<__bf16*>(ws8), z.WD, 4 * z.Hd, overlap ? side->s : c.s));
     for (int t1 = z.T; t1 > 0; t1 -= CH) {
         const int t0 = std::max(0, t1 - CH);
         hipStream_t sb = overlap ? side->s : c.s;
         for (int t = t1 - 1; t >= t0; --t) T2_TRY(dec_bwd_step(c, t));
-        T2_TRY(gemm(matmul_nn(DGd + c.R(t0) * 4 * z.Hd, 4 * z.Hd, w->dec.w_ih, z.WD, c.S(BL.ddin) + c.R(t0) * z.WD, z.WD,
-                              (t1 - t0) * z.B, z.WD, 4 * z.Hd), sb));
+        GemmDesc dd = matmul_nn(DGd + c.R(t0) * 4 * z.Hd, 4 * z.Hd, w->dec.w_ih, z.WD, c.S(BL.ddin) + c.R(t0) * z.WD, z.WD,
+                                (t1 - t0) * z.B, z.WD, 4 * z.Hd);
+        dd.ws = c.gemm_ws(); dd.ws_bytes = c.gemm_ws_bytes();             // between fork and join the scratch is chain B's
+        if (pre16) {
+            dd.B16 = reinterpret_cast<const __bf16*>(ws8); dd.ldb16 = 4 * z.Hd;
+            dd.ws = reinterpret_cast<float*>(ws8 + wt_bytes); dd.ws_bytes -= wt_bytes;
+        }
+        T2_TRY(gemm(dd, sb));
         if (overlap) T2_TRY(stream_edge(*side, ne++, sb, c.s));
         if (t0 == 0) {
             // the decoder LSTM's weight gradients need nothing from chain A: they run on chain B's stream once its
             // recurrence is done, underneath the rest of chain A (whose launches leave most CUs idle)
             const float* DG = DGd;
+            // bf16 mode: both products read ONE bf16 transpose of dG (the shifted one starts B columns in)
+            const size_t dgt_bytes = ((size_t)4 * z.Hd * BT * sizeof(__bf16) + 255) & ~(size_t)255;
+            const bool share = get_precision() == 1 && BT % 64 == 0 && z.B % 8 == 0 && (4 * z.Hd) % 128 == 0 && z.T > 1 &&
+                               c.gemm_ws_bytes() >= dgt_bytes + ((size_t)z.WD * BT * sizeof(__bf16) + 256);
+            __bf16* dgT = reinterpret_cast<__bf16*>(ws8);
+            if (share) T2_TRY(stage_bf16(DG, false, 4 * z.Hd, dgT, 4 * z.Hd, BT, sb));
+            auto with_dgT = [&](GemmDesc m, long col0) {
+                if (share) {
+                    m.A16 = dgT + col0; m.lda16 = BT;
+                    m.ws = reinterpret_cast<float*>(ws8 + dgt_bytes); m.ws_bytes = c.gemm_ws_bytes() - dgt_bytes;
+                }
+                return m;
+            };
             // dW_ih = dG^T . DIN ; recurrent half: dW_hh = dG^T . dec_h(t-1)
-            T2_TRY(gemm(matmul_tn(c, DG, 4 * z.Hd, c.W(L.din), z.WD, g->dec.w_ih, z.WD, 4 * z.Hd, z.WD, BT), sb));
+            T2_TRY(gemm(with_dgT(matmul_tn(c, DG, 4 * z.Hd, c.W(L.din), z.WD, g->dec.w_ih, z.WD, 4 * z.Hd, z.WD, BT), 0), sb));
             // h(t-1) pairs with dG(t): drop the first step's rows of dG and the last step's rows of dec_h
-            if (z.T > 1) T2_TRY(gemm(matmul_tn(c, DG + (long)z.B * 4 * z.Hd, 4 * z.Hd, c.W(L.dout), z.WO, g->dec.w_hh, z.Hd, 4 * z.Hd, z.Hd, BT - z.B), sb));
+            if (z.T > 1) T2_TRY(gemm(with_dgT(matmul_tn(c, DG + (long)z.B * 4 * z.Hd, 4 * z.Hd, c.W(L.dout), z.WO, g->dec.w_hh, z.Hd, 4 * z.Hd, z.Hd, BT - z.B), z.B), sb));
             else T2_TRY(fill_f32(g->dec.w_hh, 0.f, (size_t)4 * z.Hd * z.Hd, sb));
             T2_TRY(colsum(DG, 4 * z.Hd, BT, 4 * z.Hd, g->dec.b_ih, g->dec.b_hh, cws, sb));
         }
@@ -808,12 +846,26 @@ int t2_decoder_backward(const t2_dims* dims_in, const t2_decoder_weights* w, con
         const float* P1 = c.W(s ? L.p1s : L.p1); const float* P2 = c.W(s ? L.p2s : L.p2);
         float* dP2 = c.S(s ? BL.dp2s : BL.dp2); float* dP1 = c.S(BL.dp1);
         const long ldw = z.P + z.E;
-        // LSTM weights: W_ih = [prenet part | ctx part], W_hh, biases
-        T2_TRY(gemm(matmul_tn(c, DG, 4 * z.Ha, P2, z.P, lg.w_ih, ldw, 4 * z.Ha, z.P, BT), c.s));
+        // LSTM weights: W_ih = [prenet part | ctx part], W_hh, biases.  bf16 mode: the three products share ONE bf16
+        // transpose of dG ([4Ha][BT] at the head of the scratch; the shifted products start B columns in)
+        const size_t dgt_bytes = ((size_t)4 * z.Ha * BT * sizeof(__bf16) + 255) & ~(size_t)255;
+        const bool share = get_precision() == 1 && BT % 64 == 0 && z.B % 8 == 0 && (4 * z.Ha) % 128 == 0 && z.T > 1 &&
+                           c.gemm_ws_bytes() >= 2 * dgt_bytes;
+        __bf16* dgT = reinterpret_cast<__bf16*>(c.gemm_ws());
+        if (share) T2_TRY(stage_bf16(DG, false, 4 * z.Ha, dgT, 4 * z.Ha, BT, c.s));
+        auto dw_gemm = [&](const float* G, long col0, const float* X, long ldx, float* Y, long ldy, int N, int K) -> int {
+            GemmDesc m = matmul_tn(c, G, 4 * z.Ha, X, ldx, Y, ldy, 4 * z.Ha, N, K);
+            if (share) {
+                m.A16 = dgT + col0; m.lda16 = BT;
+                m.ws = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(c.gemm_ws()) + dgt_bytes); m.ws_bytes = c.gemm_ws_bytes() - dgt_bytes;
+            }
+            return gemm(m, c.s);
+        };
+        T2_TRY(dw_gemm(DG, 0, P2, z.P, lg.w_ih, ldw, z.P, BT));
         if (z.T > 1) {
             const float* DG1 = DG + (long)z.B * 4 * z.Ha;             // rows of steps 1..T-1 pair with ctx/h of steps 0..T-2
-            T2_TRY(gemm(matmul_tn(c, DG1, 4 * z.Ha, DIN + coff, z.WD, lg.w_ih + z.P, ldw, 4 * z.Ha, z.E, BT - z.B), c.s));
-            T2_TRY(gemm(matmul_tn(c, DG1, 4 * z.Ha, DIN + hoff, z.WD, lg.w_hh, z.Ha, 4 * z.Ha, z.Ha, BT - z.B), c.s));
+            T2_TRY(dw_gemm(DG1, z.B, DIN + coff, z.WD, lg.w_ih + z.P, ldw, z.E, BT - z.B));
+            T2_TRY(dw_gemm(DG1, z.B, DIN + hoff, z.WD, lg.w_hh, z.Ha, z.Ha, BT - z.B));
         } else {
             GemmDesc zc = matmul_tn(c, DG, 4 * z.Ha, DIN + coff, z.WD, lg.w_ih + z.P, ldw, 4 * z.Ha, z.E, BT);
             zc.alpha = 0.f;
@@ -823,7 +875,9 @@ int t2_decoder_backward(const t2_dims* dims_in, const t2_decoder_weights* w, con
         T2_TRY(colsum(DG, 4 * z.Ha, BT, 4 * z.Ha, lg.b_ih, lg.b_hh, cws, c.s));
         // prenet (model.py:13-24): dP2 = dG . W_ih[:, :P] ; through ReLU+dropout ; layer 2 ; layer 1
         const float scale = a->prenet_dropout ? 1.0f / (1.0f - dims->p_prenet_dropout) : 1.0f;
-        T2_TRY(gemm(matmul_nn(DG, 4 * z.Ha, lw.w_ih, ldw, dP2, z.P, BT, z.P, 4 * z.Ha), c.s));
+        GemmDesc gp = matmul_nn(DG, 4 * z.Ha, lw.w_ih, ldw, dP2, z.P, BT, z.P, 4 * z.Ha);
+        gp.ws = c.gemm_ws(); gp.ws_bytes = c.gemm_ws_bytes();
+        T2_TRY(gemm(gp, c.s));
         T2_TRY(relu_drop_bwd(dP2, P2, dP2, scale, (size_t)BT * z.P, c.s));
         T2_TRY(gemm(matmul_tn(c, dP2, z.P, P1, z.P, s ? g->prenet_sub_w2 : g->prenet_w2, z.P, z.P, z.P, BT), c.s));
         T2_TRY(gemm(matmul_nn(dP2, z.P, s ? w->prenet_sub_w2 : w->prenet_w2, z.P, dP1, z.P, BT, z.P, z.P), c.s));
@@ -992,6 +1046,8 @@ int t2_conv_bn_forward(const t2_conv_bn_args* a, void* stream) {
     f.training = a->training; f.eps = a->eps; f.act = a->act; f.drop_p = a->drop_p; f.seed = a->seed; f.site = a->site;
     f.residual = a->residual; f.z = a->z; f.mean = a->mean; f.invstd = a->invstd; f.var = a->var; f.y = a->y;
     f.wperm = a->ws; f.scratch = a->ws + align4(nw);
+    const size_t used = align4(nw) + 128 * (size_t)a->Cout;
+    if (a->ws_floats > used) { f.gemm_ws = a->ws + used; f.gemm_ws_bytes = (a->ws_floats - used) * sizeof(float); }
     return conv_bn_fwd(f, (hipStream_t)stream);
 }
 

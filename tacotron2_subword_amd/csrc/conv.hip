@@ -204,6 +204,7 @@ int conv_bn_fwd(const ConvBnFwd& a, hipStream_t s) {
     g.A = a.x; g.conv_a = 1; g.conv_T = a.T; g.conv_C = a.Cin; g.conv_pad = (a.K - 1) / 2;
     g.B = a.wperm; g.sbn = (long)a.K * a.Cin; g.sbk = 1;
     g.C = a.z; g.ldc = a.Cout; g.M = M; g.N = a.Cout; g.K = a.K * a.Cin; g.bias1 = a.bias;
+    g.ws = a.gemm_ws; g.ws_bytes = a.gemm_ws_bytes;
     T2_TRY_RC(gemm(g, s));
     BnElem e{a.z, a.mean, a.invstd, a.gamma, a.beta, a.Cout, a.act, a.drop_p, rng_key(a.seed, a.site)};
     if (a.training) {
@@ -253,6 +254,7 @@ int conv_bn_bwd(const ConvBnBwd& a, hipStream_t s) {
         h.B = a.wperm; h.sbn = (long)a.K * a.Cout; h.sbk = 1;
         h.C = a.dx; h.ldc = a.Cin; h.M = M; h.N = a.Cin; h.K = a.K * a.Cout;
         h.beta = a.dx_accumulate ? 1.f : 0.f;
+        h.ws = a.gemm_ws; h.ws_bytes = a.gemm_ws_bytes;
         T2_TRY_RC(gemm(h, s));
     }
     return 0;

@@ -9,10 +9,17 @@
 // Global loads are 16 B per lane along the contiguous stride; the next K-chunk is prefetched
 // into registers while the current one feeds the MFMAs (one barrier per chunk).
 #include "kernels.h"
+#include <cstdlib>
 
 namespace t2 {
 
 static int g_precision = 0;       // 0: fp32 operands (parity path), 1: bf16 operands for large GEMMs
+// bf16 mode: stage fp32 operands as bf16 copies when both extents reach g_stage_min (T2_GEMM_STAGE=0 switches it off,
+// T2_GEMM_STAGE_MIN overrides the extent)
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
+static int g_stage = env_int("T2_GEMM_STAGE", 1);
+void set_gemm_staging(int on) { g_stage = on != 0; }
+static const int g_stage_min = env_int("T2_GEMM_STAGE_MIN", 256);
 void set_precision(int p) { g_precision = p; }
 int get_precision() { return g_precision; }
 
@@ -557,6 +564,213 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmK g) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16-SOURCE variant: both operands already bf16 and K-contiguous in memory (A16 [M][lda], B16 [N][ldb]), staged by
+// the cast kernels below (or handed over by the caller).  Whole 128x128 tiles and whole 64-wide k-steps only.  Half the
+// operand bytes per MFMA of the converting kernel above and no conversion in the loop; two k-steps of 16-byte loads
+// (8 VGPRs each per operand) are kept in flight per wave.
+// ---------------------------------------------------------------------------------------------
+struct Raw16 { bf16x8 a[4], b[4]; unsigned ok; };
+// CONV_A: A16 is the bf16 copy of the frames X[M][C] and the operand is its implicit im2col (ConvAddr); C % 64 == 0, so
+// one 64-wide k-step lies inside one tap: the tile is the frame tile shifted by (tap - pad) rows, rows that leave
+// their utterance read as zero.  tpos[i] = (m0 + row_i) % T.
+template <bool CONV_A>
+__device__ __forceinline__ void issue16(const __bf16* __restrict__ A, long lda, const __bf16* __restrict__ B, long ldb, int k0,
+                                        ConvAddr cv, const int (&tpos)[4], Raw16& r) {
+    r.ok = 0xFu;
+    int shift = 0, ka = k0;
+    if constexpr (CONV_A) { const int dk = k0 / cv.C; ka = k0 - dk * cv.C; shift = dk - cv.pad; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = threadIdx.x + i * 256;
+        long row = q >> 3;
+        if constexpr (CONV_A) {
+            const bool ok = (unsigned)(tpos[i] + shift) < (unsigned)cv.T;
+            if (ok) row += shift; else r.ok &= ~(1u << i);
+        }
+        r.a[i] = *reinterpret_cast<const bf16x8*>(A + row * lda + ka + (q & 7) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = threadIdx.x + i * 256;
+        r.b[i] = *reinterpret_cast<const bf16x8*>(B + (long)(q >> 3) * ldb + k0 + (q & 7) * 8);
+    }
+}
+template <bool CONV_A>
+__device__ __forceinline__ void finish16(__bf16* __restrict__ as, __bf16* __restrict__ bs, const Raw16& r) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = threadIdx.x + i * 256;
+        bf16x8 a = r.a[i];
+        if constexpr (CONV_A) {
+            if (!((r.ok >> i) & 1u)) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = (__bf16)0.f;
+            }
+        }
+        *reinterpret_cast<bf16x8*>(as + swz16(q >> 3, q & 7)) = a;
+        *reinterpret_cast<bf16x8*>(bs + swz16(q >> 3, q & 7)) = r.b[i];
+    }
+}
+
+template <bool CONV_A>
+__global__ __launch_bounds__(256) void gemm_bf16src_kernel(GemmK g, const __bf16* __restrict__ A16, long lda, const __bf16* __restrict__ B16, long ldb) {
+    const ConvAddr cva{g.d.conv_T, g.d.conv_C, g.d.conv_pad};
+    int tpos[4] = {0, 0, 0, 0};
+    const GemmDesc& d = g.d;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    __bf16* const lds = reinterpret_cast<__bf16*>(smem16);
+    auto As = [&](int b) { return lds + b * (128 * PK16); };
+    auto Bs = [&](int b) { return lds + (2 + b) * (128 * PK16); };
+
+    const int split = blockIdx.z;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int kbeg = split * g.kchunks * BK, kend = min(d.K, kbeg + g.kchunks * BK);
+    const __bf16* A = A16 + (long)m0 * lda;
+    const __bf16* B = B16 + (long)n0 * ldb;
+    if constexpr (CONV_A) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tpos[i] = (m0 + ((int)(threadIdx.x + i * 256) >> 3)) % cva.T;
+    }
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto mma = [&](int buf) {
+        const __bf16* as = As(buf);
+        const __bf16* bs = Bs(buf);
+#pragma unroll
+        for (int ks = 0; ks < BK16 / 16; ++ks) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(as + swz16(wm * 64 + i * 32 + r, 2 * ks + h));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bs + swz16(wn * 64 + j * 32 + r, 2 * ks + h));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    const int nks = (kend - kbeg) / BK16;
+    if (nks > 0) {
+        Raw16 r0, r1;
+        issue16<CONV_A>(A, lda, B, ldb, kbeg, cva, tpos, r0);
+        if (nks > 1) issue16<CONV_A>(A, lda, B, ldb, kbeg + BK16, cva, tpos, r1);
+        finish16<CONV_A>(As(0), Bs(0), r0);
+        __syncthreads();
+        // invariant at the top of step ks: LDS buffer ks&1 holds k-step ks, `nxt` holds k-step ks+1 (in flight),
+        // `free` is empty and receives k-step ks+2 before the MFMAs
+        auto step = [&](int ks, Raw16& nxt, Raw16& free_) {
+            if (ks + 2 < nks) issue16<CONV_A>(A, lda, B, ldb, kbeg + (ks + 2) * BK16, cva, tpos, free_);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(ks & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < nks) finish16<CONV_A>(As((ks & 1) ^ 1), Bs((ks & 1) ^ 1), nxt);
+            __syncthreads();
+        };
+        int ks = 0;
+        for (; ks + 1 < nks; ks += 2) { step(ks, r1, r0); step(ks + 1, r0, r1); }
+        if (ks < nks) step(ks, r1, r0);
+    }
+
+    const RngKey key = rng_key(d.seed, d.site);
+    float* C = d.C;
+    float* ws = d.splitk > 1 ? d.ws + (long)split * (long)d.M * d.N : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (ws) ws[(long)m * d.N + n] = acc[i][j][e];
+                else epilogue_store(d, C, m, n, acc[i][j][e], key);
+            }
+        }
+}
+
+// staging casts: fp32 operand -> bf16 [rows][K] (K contiguous, leading dimension K)
+// k contiguous in the source: 8 elements per task
+__global__ void stage_kc_kernel(const float* __restrict__ src, long ld, __bf16* __restrict__ dst, int rows, int K) {
+    const int k8 = K >> 3;
+    const long total = (long)rows * k8;
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long row = t / k8; const int s = (int)(t - row * k8);
+        const float* p = src + row * ld + s * 8;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+        *reinterpret_cast<bf16x8*>(dst + row * (long)K + s * 8) = pack8(lo, hi);
+    }
+}
+// rows contiguous in the source (src[k*ld + row]): 64 k x 64 rows per workgroup through LDS
+__global__ __launch_bounds__(256) void stage_mc_kernel(const float* __restrict__ src, long ld, __bf16* __restrict__ dst, int rows, int K) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = (threadIdx.x >> 4) + 16 * i, r4 = (threadIdx.x & 15) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long)(k0 + k) * ld + r0 + r4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[k][r4 + j] = v[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int kg = threadIdx.x & 7, row = (threadIdx.x >> 3) + 32 * i;
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)tile[kg * 8 + j][row];
+        *reinterpret_cast<bf16x8*>(dst + (long)(r0 + row) * K + k0 + kg * 8) = o;
+    }
+}
+
+// implicit-im2col B operand (k = frame m, row n = tap*C + ci): dst[n][m] = X[m + tap - pad][ci] inside the utterance, else 0
+__global__ __launch_bounds__(256) void stage_conv_mc_kernel(const float* __restrict__ X, ConvAddr cv, __bf16* __restrict__ dst, int K) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const int dk = r0 / cv.C, ci0 = r0 - dk * cv.C, shift = dk - cv.pad;          // C % 64 == 0: one tap per row tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = (threadIdx.x >> 4) + 16 * i, r4 = (threadIdx.x & 15) * 4;
+        const int m = k0 + k;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)(m % cv.T + shift) < (unsigned)cv.T) v = *reinterpret_cast<const f32x4*>(X + (long)(m + shift) * cv.C + ci0 + r4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[k][r4 + j] = v[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int kg = threadIdx.x & 7, row = (threadIdx.x >> 3) + 32 * i;
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)tile[kg * 8 + j][row];
+        *reinterpret_cast<bf16x8*>(dst + (long)(r0 + row) * K + k0 + kg * 8) = o;
+    }
+}
+
+int stage_operand(const float* src, bool kc, long ld, __bf16* dst, int rows, int K, hipStream_t s) {
+    if (kc) {
+        long blocks = ((long)rows * (K >> 3) + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(stage_kc_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, ld, dst, rows, K);
+    } else {
+        hipLaunchKernelGGL(stage_mc_kernel, dim3(rows / 64, K / 64), dim3(256), 0, s, src, ld, dst, rows, K);
+    }
+    T2_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int BM, int BN>
 void launch_cfg(const GemmK& g, bool akc, bool bkc, dim3 grid, hipStream_t s) {
     if (akc && bkc) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true>), grid, dim3(256), 0, s, g);
@@ -568,6 +782,12 @@ void launch_cfg(const GemmK& g, bool akc, bool bkc, dim3 grid, hipStream_t s) {
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
+
+int stage_bf16(const float* src, bool kc, long ld, __bf16* dst, int rows, int K, hipStream_t s) {
+    T2_REQUIRE(rows > 0 && K > 0 && rows % 64 == 0 && K % 64 == 0 && ld % 4 == 0 && aligned16(src) && aligned16(dst),
+               "stage_bf16: rows=%d K=%d ld=%ld must be whole 64-tiles of 16-byte aligned rows", rows, K, ld);
+    return stage_operand(src, kc, ld, dst, rows, K, s);
+}
 
 int gemm(const GemmDesc& din, hipStream_t s) {
     GemmK g{};
@@ -593,6 +813,28 @@ int gemm(const GemmDesc& din, hipStream_t s) {
     // bf16-operand mode: large GEMMs only (both extents >= 64), conv operands need C % 8 == 0
     const bool use_bf16 = g_precision == 1 && !d.fp32_only && d.M >= 64 && d.N >= 64 && d.K >= 64 &&
                           (!(d.conv_a || d.conv_b) || d.conv_C % 8 == 0);
+    // bf16-source path: both operands staged as bf16 [rows][K] in front of the split-K scratch (or handed over by the
+    // caller); pays when each staged element is reused by many tiles, i.e. when both extents are large
+    bool staged = false;
+    __bf16* a16 = nullptr; __bf16* b16 = nullptr;
+    const bool conv_any = d.conv_a || d.conv_b;
+    if (use_bf16 && g_stage && (!conv_any || (d.conv_C % 64 == 0 && !d.A16 && !d.B16)) && d.batch == 1 && d.M % 128 == 0 && d.N % 128 == 0 && d.K % 64 == 0) {
+        // implicit-conv A: only the frames [M][C] are staged (the kernel shifts rows per tap); implicit-conv B: the whole
+        // im2col transpose [N][K] is written out (N = taps*C rows of K frames)
+        const size_t a_elems = d.conv_a ? (size_t)d.M * d.conv_C : (size_t)d.M * d.K;
+        const size_t need_a = d.A16 ? 0 : ((a_elems * sizeof(__bf16) + 255) & ~(size_t)255);
+        const size_t need_b = d.B16 ? 0 : (((size_t)d.N * d.K * sizeof(__bf16) + 255) & ~(size_t)255);
+        const bool big = (d.A16 || d.N >= g_stage_min) && (d.B16 || d.M >= g_stage_min);
+        const bool ok_src = (d.A16 || g.avec) && (d.B16 || g.bvec) &&
+                            (!d.A16 || (aligned16(d.A16) && d.lda16 % 8 == 0)) && (!d.B16 || (aligned16(d.B16) && d.ldb16 % 8 == 0));
+        if (big && ok_src && (need_a + need_b == 0 || (d.ws && aligned16(d.ws) && d.ws_bytes >= need_a + need_b))) {
+            staged = true;
+            unsigned char* base = reinterpret_cast<unsigned char*>(d.ws);
+            if (need_a) a16 = reinterpret_cast<__bf16*>(base);
+            if (need_b) b16 = reinterpret_cast<__bf16*>(base + need_a);
+            if (need_a + need_b) { d.ws = reinterpret_cast<float*>(base + need_a + need_b); d.ws_bytes -= need_a + need_b; }
+        }
+    }
     const int kch = (d.K + BK - 1) / BK;
     const bool can_split = d.ws && d.beta == 0.f && kch >= 64;
     const long tiles128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch;
@@ -622,7 +864,29 @@ int gemm(const GemmDesc& din, hipStream_t s) {
     d.splitk = splitk;
     T2_REQUIRE((long)d.batch * splitk <= 65535, "gemm: batch*splitk too large (%d*%d)", d.batch, splitk);
     dim3 grid(tn, tm, d.batch * splitk);
-    if (use_bf16) {
+    if (staged) {
+        if (a16) {
+            if (d.conv_a) T2_TRY_RC(stage_operand(d.A, true, d.conv_C, a16, d.M, d.conv_C, s));
+            else T2_TRY_RC(stage_operand(d.A, akc, akc ? d.sam : d.sak, a16, d.M, d.K, s));
+        }
+        if (b16) {
+            if (d.conv_b) {
+                hipLaunchKernelGGL(stage_conv_mc_kernel, dim3(d.N / 64, d.K / 64), dim3(256), 0, s, d.B, ConvAddr{d.conv_T, d.conv_C, d.conv_pad}, b16, d.K);
+                T2_LAUNCH_CHECK();
+            } else T2_TRY_RC(stage_operand(d.B, bkc, bkc ? d.sbn : d.sbk, b16, d.N, d.K, s));
+        }
+        const __bf16* pa = d.A16 ? d.A16 : a16; const long lda = d.A16 ? d.lda16 : (d.conv_a ? d.conv_C : d.K);
+        const __bf16* pb = d.B16 ? d.B16 : b16; const long ldb = d.B16 ? d.ldb16 : d.K;
+        const size_t smem = (size_t)4 * 128 * PK16 * sizeof(__bf16);
+        static bool attr16 = false;
+        if (!attr16) {
+            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16src_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16src_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr16 = true;
+        }
+        if (d.conv_a) hipLaunchKernelGGL(gemm_bf16src_kernel<true>, grid, dim3(256), smem, s, g, pa, lda, pb, ldb);
+        else hipLaunchKernelGGL(gemm_bf16src_kernel<false>, grid, dim3(256), smem, s, g, pa, lda, pb, ldb);
+    } else if (use_bf16) {
         const size_t smem = (size_t)4 * 128 * PK16 * sizeof(__bf16);
         static bool attr_set = false;
         if (!attr_set) {

@@ -26,6 +26,8 @@ struct GemmDesc {
     int conv_a, conv_b, conv_T, conv_C, conv_pad; // implicit im2col operand (gemm.hip ConvAddr): A rows / B k-rows are
                                                   // frames of X[B*T, C], the other index is dk*C + ci
     int fp32_only;                                // never use the bf16-operand kernel for this product
+    const __bf16* A16; long lda16;                // optional pre-staged bf16 copies of the operands, K contiguous:
+    const __bf16* B16; long ldb16;                // A16[m*lda16 + k], B16[n*ldb16 + k] (bf16 mode, whole 128x128x64 tiles)
     int crow_mod; long crow_mul;                  // output row = (m % crow_mod) * crow_mul + m / crow_mod (0 = identity):
                                                   // writes time-major rows (t,b) in batch-major order (b,t) or back
 };
@@ -33,8 +35,12 @@ inline GemmDesc gemm_desc() {
     GemmDesc d{}; d.batch = 1; d.alpha = 1.f; d.beta = 0.f; d.act = ACT_NONE; d.drop_p = 0.f; return d;
 }
 int gemm(const GemmDesc& d, hipStream_t s);
+// bf16 copy of an fp32 operand, K contiguous: dst[row*K + k] = src[row*ld + k] (kc) or src[k*ld + row] (!kc);
+// rows % 64 == 0, K % 64 == 0, 16-byte aligned rows.  For GemmDesc::A16 / B16 shared by several products.
+int stage_bf16(const float* src, bool kc, long ld, __bf16* dst, int rows, int K, hipStream_t s);
 void set_precision(int p);   // 0 fp32 operands, 1 bf16 operands (fp32 accumulate) for large GEMMs and LSTM steps
 int get_precision();
+void set_gemm_staging(int on);   // bf16 mode: stage fp32 operands as bf16 copies for the bf16-source kernel (default on)
 
 // ------------------------------------------------------------------ LSTM (lstm.hip)
 constexpr int kMaxSeg = 6;
@@ -205,6 +211,7 @@ struct ConvBnFwd {
     float* z; float* mean; float* invstd; float* var;   // saved: conv+bias output [B*T,Cout], batch (or running) stats [Cout]
     float* y;                                    // [B*T, Cout]
     float* wperm; float* scratch;                // [Cout*Cin*K], [128*Cout]
+    float* gemm_ws; size_t gemm_ws_bytes;        // optional: bf16 operand staging (gemm.hip)
 };
 int conv_bn_fwd(const ConvBnFwd& a, hipStream_t s);
 struct ConvBnBwd {

@@ -105,6 +105,40 @@ def test_conv_bn_stack_vs_oracle(env, kind, training):
             assert int(dbns[i].num_batches_tracked) == int(bns[i].num_batches_tracked) + 1
 
 
+@pytest.mark.parametrize("training", [False, True])
+def test_conv_bn_stack_bf16_staged_vs_converting(env, training):
+    """bf16 mode, whole-tile shapes: the conv GEMMs (forward, d(input), d(weight)) on staged bf16 operands (frames staged
+    once, taps as row shifts; im2col transpose written out for d(weight)) against the same GEMMs on the converting
+    kernel — same operand rounding, so they agree to summation order, utterance edges included."""
+    L, blocks, ops = env
+    g = torch.Generator().manual_seed(11)
+    B, T = 2, 128
+    chans, acts = [128, 256, 256], [1, 2]
+    convs = [torch.nn.Conv1d(chans[i], chans[i + 1], 5, padding=2).cuda() for i in range(2)]
+    bns = [torch.nn.BatchNorm1d(chans[i + 1]).cuda() for i in range(2)]
+    x0 = torch.randn(B, T, chans[0], generator=g).cuda()
+    R = torch.randn(B, T, chans[-1], generator=g).cuda()
+    res = {}
+    L.set_precision("bf16")
+    try:
+        for on in (1, 0):
+            L.check(L.lib().t2_set_gemm_staging(on))
+            for m_ in convs + bns:
+                m_.zero_grad()
+            for bn in bns:
+                bn.running_mean.zero_(); bn.running_var.fill_(1.0)
+            xd = x0.clone().requires_grad_(True)
+            y = blocks.conv_bn_stack(xd, list(zip(convs, bns)), acts, training=training, drop_p=0.5, seed=77, site0=L.SITE["ENC0"])
+            (y * R).sum().backward()
+            res[on] = [y.detach().clone(), xd.grad.clone()] + [c.weight.grad.clone() for c in convs] + [c.bias.grad.clone() for c in convs]
+    finally:
+        L.check(L.lib().t2_set_gemm_staging(1))
+        L.set_precision("f32")
+    for a, b in zip(res[1], res[0]):
+        assert torch.isfinite(a).all()
+        assert rel(a, b) < 2e-4
+
+
 @pytest.mark.parametrize("packed", [True, False])
 def test_bilstm_vs_oracle(env, packed):
     L, blocks, ops = env

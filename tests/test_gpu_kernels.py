@@ -104,3 +104,27 @@ def test_gemm_bf16_operands(ops, M, N, K, ta, tb):
     assert (C.double().cpu() - ref).abs().max().item() < 2e-3 * max(1.0, K ** 0.5 / 8)
     assert (C2.double().cpu() - ref).abs().max().item() < 2e-3 * max(1.0, K ** 0.5 / 8)
     assert L.get_precision() == "f32"
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 384, 192), (512, 256, 4096), (1024, 640, 64)])
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, True), (True, False)])
+def test_gemm_bf16_staged_operands(ops, M, N, K, ta, tb):
+    """bf16 mode with scratch: whole-tile shapes take the bf16-source kernel (operands staged as bf16 copies, split-K for
+    the long K); same contract as the converting kernel, and the two agree to summation order."""
+    from tacotron2_subword_amd import _lib as L
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    A = torch.randn((K, M) if ta else (M, K), generator=g).cuda()
+    B = torch.randn((N, K) if tb else (K, N), generator=g).cuda()
+    ws = torch.empty(8 * M * N + (M + N) * K, device="cuda")
+    bias = torch.randn(N, generator=g).cuda()
+    L.set_precision("bf16")
+    try:
+        C1 = ops.gemm(A, B, trans_a=ta, trans_b=tb, ws=ws, bias=bias)
+        L.check(L.lib().t2_set_gemm_staging(0))
+        C0 = ops.gemm(A, B, trans_a=ta, trans_b=tb, ws=ws, bias=bias)
+    finally:
+        L.check(L.lib().t2_set_gemm_staging(1))
+        L.set_precision("f32")
+    ref = _ref(A.bfloat16().float(), B.bfloat16().float(), ta, tb) + bias.double().cpu()
+    assert (C1.double().cpu() - ref).abs().max().item() < 2e-3 * max(1.0, K ** 0.5 / 8)
+    assert (C1 - C0).abs().max().item() < 1e-4 * max(1.0, K ** 0.5)

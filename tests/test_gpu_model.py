@@ -53,25 +53,33 @@ def test_backward_eval_mode_vs_oracle_autograd(att):
     out = m(x)
     loss = Tacotron2Loss()(out, y, x)[0]
     loss.backward()
-    # oracle
-    P = recipe.make_weights(hp)
-    for k, v in P.items():
-        if v.is_floating_point() and "running" not in k:
-            v.requires_grad_(True)
-    xo, yo = recipe.parse_batch(batch)
-    oo = O.forward(P, hp, xo, training=False)
-    lo = O.loss(oo, yo)[0]
-    lo.backward()
-    assert abs(float(loss.detach()) - float(lo.detach())) < 1e-5
+    # oracle: fp32 autograd for the loss value, fp64 autograd as the gradient ground truth.  A parameter whose
+    # gradient is a small remainder of cancelling terms (DCA's T.bias: 1e-3 relative between the oracle's own fp32
+    # and fp64 results) is held to 3x the fp32 oracle's error instead of the flat bound.
+    def oracle_grads(dt):
+        P = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in recipe.make_weights(hp).items()}
+        for k, v in P.items():
+            if v.is_floating_point() and "running" not in k:
+                v.requires_grad_(True)
+        cast = lambda ts: tuple(t.to(dt) if torch.is_tensor(t) and t.is_floating_point() else t for t in ts)
+        xo, yo = recipe.parse_batch(batch)
+        lo = O.loss(O.forward(P, hp, cast(xo), training=False), cast(yo))[0]
+        lo.backward()
+        return float(lo.detach()), {k: (None if v.grad is None else v.grad.double()) for k, v in P.items() if v.is_floating_point()}
+    lo32, g32 = oracle_grads(torch.float32)
+    _, g64 = oracle_grads(torch.float64)
+    assert abs(float(loss.detach()) - lo32) < 1e-5
     bad = {}
     for k, p in m.named_parameters():
-        ref = P[k].grad
+        ref = g64[k]
         if ref is None:
             assert p.grad is None, k                 # dead decoder_rnn_bert
             continue
-        err = maxabs(p.grad, ref) / max(float(ref.abs().max()), 1e-7)
-        if not err < 5e-4:
-            bad[k] = err
+        scale = max(float(ref.abs().max()), 1e-7)
+        err = float((p.grad.double().cpu() - ref).abs().max()) / scale
+        noise = float((g32[k] - ref).abs().max()) / scale
+        if not err < max(5e-4, 3 * noise):
+            bad[k] = (err, noise)
     assert not bad, bad
 
 
@@ -165,7 +173,12 @@ def test_training_mode_full_model_vs_oracle(att):
         if ref is None:
             assert p.grad is None, k
             continue
-        # conv biases feeding a train-mode BatchNorm have a mathematically zero gradient: absolute floor
+        # conv biases feeding a train-mode BatchNorm have a mathematically zero gradient (both sides hold rounding
+        # noise of the column sums, ~1e-7): absolute bound for them, relative for everything else
+        if k.endswith("conv.bias") and float(ref.abs().max()) < 1e-5:
+            if not maxabs(p.grad, ref) < 1e-6:
+                bad[k] = maxabs(p.grad, ref)
+            continue
         err = maxabs(p.grad, ref) / max(float(ref.abs().max()), 1e-4)
         if not err < 1e-3:
             bad[k] = err
