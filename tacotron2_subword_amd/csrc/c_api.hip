@@ -634,6 +634,27 @@ int att_bwd_step(const Bwd& c, int t) {
 
 }  // namespace
 
+// Step ranges handed from one chain to the other.  One range when the chains share a stream; otherwise about eight,
+// with short ranges (16, 32 steps) at the END of time: that is where the forward pass's decoder-LSTM chain finishes
+// after the attention chain, and where the backward pass's attention chain waits for the first decoder-LSTM range,
+// so whatever the last range holds is exposed.  Even boundaries keep rows-per-range a multiple of 128 at B = 64.
+static std::vector<int> chunk_bounds(int T, bool overlap) {
+    std::vector<int> b{0};
+    if (!overlap) { b.push_back(T); return b; }
+    const int CH = std::max(16, (T + 7) / 8);
+    std::vector<int> tail;
+    int rem = T;
+    for (int s = 16; s < CH && rem - s >= CH; s *= 2) { tail.push_back(s); rem -= s; }
+    const int n = std::max(1, rem / CH);
+    for (int i = 1; i < n; ++i) {
+        const int e = (int)((long)rem * i / n) & ~1;
+        if (e > b.back()) b.push_back(e);
+    }
+    b.push_back(rem);
+    for (auto it = tail.rbegin(); it != tail.rend(); ++it) b.push_back(b.back() + *it);
+    return b;
+}
+
 extern "C" {
 
 const char* t2_last_error(void) { return g_err; }
@@ -699,7 +720,7 @@ int t2_decoder_forward(const t2_dims* dims_in, const t2_decoder_weights* w, cons
     Side* side = nullptr;
     const bool overlap = g_overlap && z.T >= 32;
     if (overlap) { T2_TRY(side_get(&side)); c.sd = side->s; }
-    const int CH = overlap ? std::max(16, (z.T + 7) / 8) : z.T;
+    const std::vector<int> bounds = chunk_bounds(z.T, overlap);
     size_t ne = 0;
     // bf16 steps keep a bf16 shadow of every DIN row (din16): with one bf16 copy of W_ih at the head of the scratch the
     // chunk GEMMs below read both operands as bf16 and stage nothing
@@ -707,8 +728,8 @@ int t2_decoder_forward(const t2_dims* dims_in, const t2_decoder_weights* w, cons
     const bool pre16 = c.use16 && (4 * z.Hd) % 64 == 0 && z.WD % 64 == 0 && L.gemm_ws_floats * sizeof(float) > w16_bytes;
     __bf16* w16 = reinterpret_cast<__bf16*>(c.P(L.gemm_ws));
     if (pre16) T2_TRY(stage_bf16(w->dec.w_ih, true, z.WD, w16, 4 * z.Hd, z.WD, c.s));
-    for (int t0 = 0; t0 < z.T; t0 += CH) {
-        const int t1 = std::min(z.T, t0 + CH);
+    for (size_t ci = 0; ci + 1 < bounds.size(); ++ci) {
+        const int t0 = bounds[ci], t1 = bounds[ci + 1];
         for (int t = t0; t < t1; ++t) {
             T2_TRY(att_lstm_step(c, t));
             T2_TRY(attention_step(c, t));
@@ -787,15 +808,15 @@ int t2_decoder_backward(const t2_dims* dims_in, const t2_decoder_weights* w, con
         T2_TRY(side_get(&side)); c.sd = side->s;
         T2_TRY(stream_edge(*side, ne++, c.s, side->s));                 // fork: dDOUT is complete
     }
-    const int CH = overlap ? std::max(16, (z.T + 7) / 8) : z.T;
+    const std::vector<int> bounds = chunk_bounds(z.T, overlap);
     const float* DGd = c.S(BL.dgd);
     // bf16 mode: W_ih^T ([WD][4Hd], K contiguous) is staged once at the head of the scratch for all dDIN chunks
     unsigned char* const ws8 = reinterpret_cast<unsigned char*>(c.gemm_ws());
     const size_t wt_bytes = ((size_t)4 * z.Hd * z.WD * sizeof(__bf16) + 255) & ~(size_t)255;
     const bool pre16 = get_precision() == 1 && (4 * z.Hd) % 64 == 0 && z.WD % 64 == 0 && c.gemm_ws_bytes() > 2 * wt_bytes;
     if (pre16) T2_TRY(stage_bf16(w->dec.w_ih, false, z.WD, reinterpret_cast<__bf16*>(ws8), z.WD, 4 * z.Hd, overlap ? side->s : c.s));
-    for (int t1 = z.T; t1 > 0; t1 -= CH) {
-        const int t0 = std::max(0, t1 - CH);
+    for (size_t ci = bounds.size() - 1; ci > 0; --ci) {
+        const int t0 = bounds[ci - 1], t1 = bounds[ci];
         hipStream_t sb = overlap ? side->s : c.s;
         for (int t = t1 - 1; t >= t0; --t) T2_TRY(dec_bwd_step(c, t));
         GemmDesc dd = matmul_nn(DGd + c.R(t0) * 4 * z.Hd, 4 * z.Hd, w->dec.w_ih, z.WD, c.S(BL.ddin) + c.R(t0) * z.WD, z.WD,
