@@ -145,6 +145,10 @@ typedef struct t2_decoder_fwd_args {
     int training;             /* LSTM-state dropout + SMA noise on (model.train()) */
     int prenet_dropout;       /* 1 = reference behaviour (always on, model.py:23); 0 = off for deterministic parity */
     uint64_t seed;
+    int phase;                /* 0: the whole pass.  1: only the part that does not read the memories (bf16 shadows, teacher
+                               * inputs, both prenets, hoisted attention-LSTM input GEMMs) — may run on another stream while
+                               * the encoders are still working.  2: the rest, on a workspace phase 1 has filled (the caller
+                               * orders the two calls, e.g. with an event). */
 } t2_decoder_fwd_args;
 int t2_decoder_forward(const t2_dims* dims, const t2_decoder_weights* w, const t2_decoder_fwd_args* a, void* stream);
 

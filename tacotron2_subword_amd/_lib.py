@@ -61,7 +61,7 @@ class DecoderFwdArgs(C.Structure):
                 ("memory", C.c_void_p), ("memory_sub", C.c_void_p), ("mem_lengths", C.c_void_p), ("sub_lengths", C.c_void_p),
                 ("mels", C.c_void_p), ("mel_out", C.c_void_p), ("gate_out", C.c_void_p), ("align", C.c_void_p),
                 ("align_sub", C.c_void_p), ("ws", C.c_void_p), ("training", C.c_int), ("prenet_dropout", C.c_int),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("phase", C.c_int)]
 
 
 class DecoderInferArgs(C.Structure):

@@ -698,21 +698,31 @@ int t2_decoder_forward(const t2_dims* dims_in, const t2_decoder_weights* w, cons
     const Sizes& z = c.z; const t2_decoder_layout& L = c.L;
     const int BT = z.B * z.T;
 
+    T2_REQUIRE(a->phase >= 0 && a->phase <= 2, "t2_decoder_forward: phase must be 0, 1 or 2");
     c.use16 = use_bf16_steps(*dims, z);
-    if (c.use16) T2_TRY(cast_shadows(*dims, *w, z, L, a->ws, c.s));
-    // teacher inputs and both prenets over all frames (model.py:407-413)
-    T2_TRY(teacher_inputs(a->mels, c.P(L.x), z.B, z.M, z.T, c.s));
-    T2_TRY(prenet(c, false, c.P(L.x), z.M, BT, c.P(L.p1), c.P(L.p2), z.P, 0, 0));      // rows time-major: (t,b)
-    if (z.NS == 2) T2_TRY(prenet(c, true, c.P(L.x), z.M, BT, c.P(L.p1s), c.P(L.p2s), z.P, 0, 0));
-    T2_TRY(processed_memory(c));                                    // model.py:258,261
-    // hoisted input half of both attention LSTMs:  P2 . W_ih[:, :P]^T + b_ih + b_hh
-    for (int s = 0; s < z.NS; ++s) {
-        const t2_lstm_weights& lw = s ? w->att_sub : w->att;
-        GemmDesc g = linear(c.P(s ? L.p2s : L.p2), z.P, lw.w_ih, z.P + z.E, c.P(s ? L.preas : L.prea), 4 * z.Ha, BT, 4 * z.Ha, z.P);
-        g.bias1 = lw.b_ih; g.bias2 = lw.b_hh;
-        g.ws = c.P(L.gemm_ws); g.ws_bytes = L.gemm_ws_floats * sizeof(float);       // bf16 staging (gemm.hip)
-        T2_TRY(gemm(g, c.s));
+    // bf16 steps keep a bf16 shadow of every DIN row (din16): with one bf16 copy of W_ih at the head of the scratch the
+    // decoder-LSTM input GEMMs below read both operands as bf16 and stage nothing
+    const size_t w16_bytes = ((size_t)4 * z.Hd * z.WD * sizeof(__bf16) + 255) & ~(size_t)255;
+    const bool pre16 = c.use16 && (4 * z.Hd) % 64 == 0 && z.WD % 64 == 0 && L.gemm_ws_floats * sizeof(float) > w16_bytes;
+    __bf16* w16 = reinterpret_cast<__bf16*>(c.P(L.gemm_ws));
+    if (a->phase != 2) {                                                // ---- everything that does not read the memories
+        if (c.use16) T2_TRY(cast_shadows(*dims, *w, z, L, a->ws, c.s));
+        // teacher inputs and both prenets over all frames (model.py:407-413)
+        T2_TRY(teacher_inputs(a->mels, c.P(L.x), z.B, z.M, z.T, c.s));
+        T2_TRY(prenet(c, false, c.P(L.x), z.M, BT, c.P(L.p1), c.P(L.p2), z.P, 0, 0));      // rows time-major: (t,b)
+        if (z.NS == 2) T2_TRY(prenet(c, true, c.P(L.x), z.M, BT, c.P(L.p1s), c.P(L.p2s), z.P, 0, 0));
+        // hoisted input half of both attention LSTMs:  P2 . W_ih[:, :P]^T + b_ih + b_hh
+        for (int s = 0; s < z.NS; ++s) {
+            const t2_lstm_weights& lw = s ? w->att_sub : w->att;
+            GemmDesc g = linear(c.P(s ? L.p2s : L.p2), z.P, lw.w_ih, z.P + z.E, c.P(s ? L.preas : L.prea), 4 * z.Ha, BT, 4 * z.Ha, z.P);
+            g.bias1 = lw.b_ih; g.bias2 = lw.b_hh;
+            g.ws = c.P(L.gemm_ws); g.ws_bytes = L.gemm_ws_floats * sizeof(float);       // bf16 staging (gemm.hip)
+            T2_TRY(gemm(g, c.s));
+        }
+        if (pre16) T2_TRY(stage_bf16(w->dec.w_ih, true, z.WD, w16, 4 * z.Hd, z.WD, c.s));
+        if (a->phase == 1) return 0;
     }
+    T2_TRY(processed_memory(c));                                    // model.py:258,261
     // Two serial chains, overlapped in chunks of steps:
     //   A (caller's stream): attention LSTMs + attention — the only truly recurrent chain through the contexts
     //   B (side stream):     hoisted input half of the decoder LSTM for the chunk A just finished
@@ -722,12 +732,6 @@ int t2_decoder_forward(const t2_dims* dims_in, const t2_decoder_weights* w, cons
     if (overlap) { T2_TRY(side_get(&side)); c.sd = side->s; }
     const std::vector<int> bounds = chunk_bounds(z.T, overlap);
     size_t ne = 0;
-    // bf16 steps keep a bf16 shadow of every DIN row (din16): with one bf16 copy of W_ih at the head of the scratch the
-    // chunk GEMMs below read both operands as bf16 and stage nothing
-    const size_t w16_bytes = ((size_t)4 * z.Hd * z.WD * sizeof(__bf16) + 255) & ~(size_t)255;
-    const bool pre16 = c.use16 && (4 * z.Hd) % 64 == 0 && z.WD % 64 == 0 && L.gemm_ws_floats * sizeof(float) > w16_bytes;
-    __bf16* w16 = reinterpret_cast<__bf16*>(c.P(L.gemm_ws));
-    if (pre16) T2_TRY(stage_bf16(w->dec.w_ih, true, z.WD, w16, 4 * z.Hd, z.WD, c.s));
     for (size_t ci = 0; ci + 1 < bounds.size(); ++ci) {
         const int t0 = bounds[ci], t1 = bounds[ci + 1];
         for (int t = t0; t < t1; ++t) {

@@ -124,8 +124,13 @@ class _DecoderFn(torch.autograd.Function):
         W = L.decoder_weights(P, dims.attention_kind, single=dec.single)
         memory, mels = memory.contiguous(), mels.contiguous()
         memory_sub = None if memory_sub is None else memory_sub.contiguous()
+        pre = cfg.get("pre")
+        if pre is not None:                     # Decoder.prologue ran the memory-independent part on its own stream
+            torch.cuda.current_stream().wait_event(pre["event"])
         dp = ops.decoder_forward(W, dims, memory, memory_sub, mem_lengths, sub_lengths, mels,
-                                 training=cfg["training"], prenet_dropout=cfg["prenet_dropout"], seed=cfg["seed"])
+                                 training=cfg["training"], prenet_dropout=cfg["prenet_dropout"], seed=cfg["seed"],
+                                 dp=None if pre is None else pre["dp"])
+        cfg.pop("pre", None)
         ctx.cfg, ctx.dp, ctx.P, ctx.W = cfg, dp, P, W
         ctx.save_for_backward(*((memory,) if memory_sub is None else (memory, memory_sub)))
         ctx.set_materialize_grads(False)
@@ -206,12 +211,40 @@ class Decoder(nn.Module):
         P.update({"decoder." + k: v for k, v in self.named_buffers()})           # DCA prior taps
         return P, L.decoder_weights(P, self.dims.attention_kind, single=self.single)
 
+    def prologue(self, decoder_inputs, B, Tin, Tsub):
+        """Start the part of forward() that needs no encoder output — teacher inputs, both prenets, the hoisted
+        attention-LSTM input GEMMs (about 1 ms of chip-filling GEMMs at B=64, T=400) — on a side stream, so that it runs
+        underneath the encoders' chains of small launches.  Returns the handle forward(pre=...) takes."""
+        seed = self._next_seed()
+        mels = decoder_inputs.contiguous()
+        _, W = self._weights()
+        dp = ops.DecoderPass(self.dims, B, mels.shape[2], Tin, Tsub, mels.device)      # allocated on the caller's stream
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_pro_stream", None) is None:
+            self._pro_stream = torch.cuda.Stream(device=mels.device)
+        self._pro_stream.wait_stream(cur)
+        with torch.cuda.stream(self._pro_stream):
+            ops.decoder_prologue(W, self.dims, dp, mels, training=self.training, prenet_dropout=self.prenet_dropout, seed=seed)
+            event = torch.cuda.Event()
+            event.record()
+        return dict(dp=dp, seed=seed, event=event, mels=mels, training=self.training, prenet_dropout=self.prenet_dropout)
+
     # -- reference surface -----------------------------------------------------------------
-    def forward(self, memory, embeddings, decoder_inputs, memory_lengths, bert_lengths, channels_last=False):
+    def forward(self, memory, embeddings, decoder_inputs, memory_lengths, bert_lengths, channels_last=False, pre=None):
         """Decoder.forward (model.py:392-428): returns mel [B,n_mel,T] ([B,T,n_mel] if channels_last),
-        gate [B,T], align [B,T,Tin], align_bert [B,T,Tsub]."""
+        gate [B,T], align [B,T,Tin], align_bert [B,T,Tsub].  pre: handle of prologue() for the same inputs."""
+        if pre is not None:
+            dp = pre["dp"]
+            same = (dp.B, dp.T, dp.Tin) == (memory.shape[0], decoder_inputs.shape[2], memory.shape[1]) and \
+                   (embeddings is None or dp.Tsub == embeddings.shape[1]) and pre["training"] == self.training and \
+                   pre["prenet_dropout"] == self.prenet_dropout
+            if not same:                        # shapes changed in between: wait the side work out and run the whole pass
+                torch.cuda.current_stream().wait_event(pre["event"])
+                pre = dict(seed=pre["seed"])
         cfg = dict(decoder=self, keys=self._param_keys(), training=self.training, prenet_dropout=self.prenet_dropout,
-                   seed=self._next_seed())
+                   seed=self._next_seed() if pre is None else pre["seed"])
+        if pre is not None and "dp" in pre:
+            cfg["pre"] = pre
         mel, gate, al, alb = _DecoderFn.apply(memory, embeddings, decoder_inputs, memory_lengths, bert_lengths, cfg,
                                               *self._params())
         return (mel if channels_last else mel.transpose(1, 2)), gate, al, alb
@@ -303,8 +336,11 @@ class BERT_Tacotron2(nn.Module):
         text, tl, bl, mels, _, ol, sub_ids, pcls, bcls = inputs
         tl, bl, ol = tl.data, bl.data, ol.data
         seed = _next_seed(self)
+        pre = None
+        if self.overlap_encoders and text.is_cuda:                              # decoder prologue underneath the encoders
+            pre = self.decoder.prologue(mels, text.shape[0], text.shape[1], sub_ids.shape[1])
         memory, memory_sub = self._fronts(text, tl, pcls, sub_ids, bl, bcls, seed)
-        mel_btc, gate, al, alb = self.decoder(memory, memory_sub, mels, tl, bl, channels_last=True)
+        mel_btc, gate, al, alb = self.decoder(memory, memory_sub, mels, tl, bl, channels_last=True, pre=pre)
         post_btc = self.postnet.forward_btc(mel_btc, seed)                      # mel + postnet(mel), [B,T,n_mel]
         if self.mask_padding and ol is not None:
             mel = _FinalizeFn.apply(mel_btc, ol, 0.0)

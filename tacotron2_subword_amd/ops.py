@@ -63,18 +63,32 @@ class DecoderPass:
 
 
 def decoder_forward(W: L.DecoderWeights, dims: L.Dims, memory, memory_sub, mem_lengths, sub_lengths, mels, *,
-                    training: bool, prenet_dropout: bool, seed: int, keep=None) -> DecoderPass:
-    """Teacher-forced decoder (Decoder.forward, model.py:392-428).  mels: [B,n_mel,T]."""
+                    training: bool, prenet_dropout: bool, seed: int, keep=None, dp: Optional[DecoderPass] = None) -> DecoderPass:
+    """Teacher-forced decoder (Decoder.forward, model.py:392-428).  mels: [B,n_mel,T].  dp: a pass whose
+    memory-independent part decoder_prologue has already run (the caller has ordered the streams)."""
     B, Tin, _ = memory.shape
     Tsub, T = (1 if memory_sub is None else memory_sub.shape[1]), mels.shape[2]     # single-stream: no second memory
-    dp = DecoderPass(dims, B, T, Tin, Tsub, memory.device)
+    phase = 0 if dp is None else 2
+    if dp is None:
+        dp = DecoderPass(dims, B, T, Tin, Tsub, memory.device)
+    assert (dp.B, dp.T, dp.Tin, dp.Tsub) == (B, T, Tin, Tsub)
     ml, sl = _i32(mem_lengths), _i32(sub_lengths)
     a = L.DecoderFwdArgs(B, T, Tin, Tsub, L.ptr(memory), L.ptr(memory_sub), L.ptr(ml), L.ptr(sl), L.ptr(mels),
                          L.ptr(dp.mel), L.ptr(dp.gate), L.ptr(dp.align), L.ptr(dp.align_sub), L.ptr(dp.ws),
-                         int(training), int(prenet_dropout), seed)
+                         int(training), int(prenet_dropout), seed, phase)
     L.check(L.lib().t2_decoder_forward(C.byref(dims), C.byref(W), C.byref(a), L.stream()))
     dp._keep = (ml, sl, keep)
     return dp
+
+
+def decoder_prologue(W: L.DecoderWeights, dims: L.Dims, dp: DecoderPass, mels, *, training: bool, prenet_dropout: bool,
+                     seed: int) -> None:
+    """The part of decoder_forward that needs no encoder output (teacher inputs, prenets, hoisted attention-LSTM input
+    GEMMs, bf16 shadows), on the CURRENT stream: t2_decoder_forward phase 1."""
+    a = L.DecoderFwdArgs(dp.B, dp.T, dp.Tin, dp.Tsub, None, None, None, None, L.ptr(mels),
+                         L.ptr(dp.mel), L.ptr(dp.gate), L.ptr(dp.align), L.ptr(dp.align_sub), L.ptr(dp.ws),
+                         int(training), int(prenet_dropout), seed, 1)
+    L.check(L.lib().t2_decoder_forward(C.byref(dims), C.byref(W), C.byref(a), L.stream()))
 
 
 def decoder_backward(W: L.DecoderWeights, P: dict, dims: L.Dims, dp: DecoderPass, memory, memory_sub, d_mel, d_gate, *,
