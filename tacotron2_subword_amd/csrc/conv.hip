@@ -96,9 +96,22 @@ __global__ void colreduce_stage2_kernel(const float* __restrict__ scratch, int C
                                         float* out0, float* out1) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    float s0 = 0.f, s1 = 0.f;
-    for (int s = 0; s < slabs; ++s) s0 += scratch[(size_t)s * C + c];
-    if (mode == 2) for (int s = 0; s < slabs; ++s) s1 += scratch[(size_t)(slabs + s) * C + c];
+    // the slab partials are requested 16 at a time and added in slab order (one dependent load per slab cost 0.3 us each)
+    auto ordered_sum = [&](const float* __restrict__ p) {
+        float acc = 0.f;
+        int s = 0;
+        for (; s + 16 <= slabs; s += 16) {
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = p[(size_t)(s + j) * C];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc += v[j];
+        }
+        for (; s < slabs; ++s) acc += p[(size_t)s * C];
+        return acc;
+    };
+    const float s0 = ordered_sum(scratch + c);
+    const float s1 = mode == 2 ? ordered_sum(scratch + (size_t)slabs * C + c) : 0.f;
     if (mode == 0) out0[c] = s0 / (float)M;
     else if (mode == 1) { const float var = s0 / (float)M; out0[c] = 1.0f / sqrtf(var + eps); if (out1) out1[c] = var; }
     else { out0[c] = s0; out1[c] = s1; }
@@ -155,28 +168,40 @@ __global__ void embedding_fwd_kernel(const long* __restrict__ ids, const float* 
 __global__ void embedding_bwd_kernel(const long* __restrict__ ids, const float* __restrict__ dout, float* __restrict__ dtable, int rows, int D) {
     const int v = blockIdx.x;
     extern __shared__ int hits[];
-    __shared__ int nhit;
-    __shared__ int wave_cnt[16];
-    if (threadIdx.x == 0) nhit = 0;
-    __syncthreads();
-    for (int r0 = 0; r0 < rows; r0 += blockDim.x) {
-        const int r = r0 + threadIdx.x;
-        // ordered compaction keeps the summation order independent of scheduling
-        const bool hit = r < rows && ids[r] == v;
+    __shared__ int wave_cnt[2][16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    // ordered compaction of the rows that hit v (keeps the summation order independent of scheduling): every thread
+    // carries the running count, the next block of ids is requested before the current one is processed, one barrier
+    // per block of rows
+    int run = 0;
+    long idn = (int)threadIdx.x < rows ? ids[threadIdx.x] : -1;
+    for (int r0 = 0, it = 0; r0 < rows; r0 += blockDim.x, ++it) {
+        const int r = r0 + threadIdx.x, rn = r + blockDim.x;
+        const long id = idn;
+        idn = rn < rows ? ids[rn] : -1;
+        const bool hit = r < rows && id == v;
         const unsigned long long m = __ballot(hit);
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        int* wc = wave_cnt[it & 1];
+        if (lane == 0) wc[wave] = __popcll(m);
         __syncthreads();
-        int base = nhit;
-        for (int w = 0; w < wave; ++w) base += wave_cnt[w];
+        int base = run, tot = 0;
+        for (int w = 0; w < nw; ++w) { const int cw = wc[w]; if (w < wave) base += cw; tot += cw; }
         if (hit) hits[base + __popcll(m & ((1ull << lane) - 1ull))] = r;
-        __syncthreads();
-        if (threadIdx.x == 0) { int tot = 0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += wave_cnt[w]; nhit += tot; }
-        __syncthreads();
+        run += tot;
     }
+    __syncthreads();
+    const int nhit = run;
     for (int c = threadIdx.x; c < D; c += blockDim.x) {
-        float acc = 0.f;
-        for (int h = 0; h < nhit; ++h) acc += dout[(size_t)hits[h] * D + c];
+        float acc = 0.f;                                   // rows requested 8 at a time, added in row order
+        int h = 0;
+        for (; h + 8 <= nhit; h += 8) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = dout[(size_t)hits[h + j] * D + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += x[j];
+        }
+        for (; h < nhit; ++h) acc += dout[(size_t)hits[h] * D + c];
         dtable[(size_t)v * D + c] = acc;
     }
 }

@@ -104,11 +104,25 @@ __global__ void colsum_stage1_kernel(const float* __restrict__ X, long ld, int M
     __syncthreads();
     if (sub == 0 && n < N) scratch[(long)blockIdx.y * N + n] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
+// sum_{s < count} p[s * stride], terms requested 16 at a time and added in index order (a dependent load per term
+// costs ~0.3 us each: 20 us for 64 slabs)
+__device__ __forceinline__ float ordered_sum16(const float* __restrict__ p, int count, long stride) {
+    float acc = 0.f;
+    int s = 0;
+    for (; s + 16 <= count; s += 16) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = p[(long)(s + j) * stride];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc += v[j];
+    }
+    for (; s < count; ++s) acc += p[(long)s * stride];
+    return acc;
+}
 __global__ void colsum_stage2_kernel(const float* __restrict__ scratch, int N, int slabs, float* out, float* out2) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    float acc = 0.f;
-    for (int s = 0; s < slabs; ++s) acc += scratch[(long)s * N + n];
+    const float acc = ordered_sum16(scratch + n, slabs, N);
     out[n] = acc;
     if (out2) out2[n] = acc;
 }
@@ -122,9 +136,7 @@ __global__ void fold_halves_kernel(float* __restrict__ X, size_t rows, int A) {
 __global__ void batch_sum_kernel(const float* __restrict__ X, int B, int n, float* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc += X[(long)b * n + i];
-    out[i] = acc;
+    out[i] = ordered_sum16(X + i, B, n);
 }
 
 }  // namespace

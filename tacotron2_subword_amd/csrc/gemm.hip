@@ -228,8 +228,24 @@ __global__ void splitk_reduce_kernel(GemmDesc d) {
     const long total = (long)d.batch * d.M * d.N;
     const RngKey key = rng_key(d.seed, d.site);
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        float acc = 0.f;
-        for (int s = 0; s < d.splitk; ++s) acc += d.ws[(long)s * total + i];
+        float acc = 0.f;                                   // partials requested 8 at a time, added in split order
+        int s = 0;
+        for (; s + 8 <= d.splitk; s += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = d.ws[(long)(s + j) * total + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += v[j];
+        }
+        if (s + 4 <= d.splitk) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = d.ws[(long)(s + j) * total + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc += v[j];
+            s += 4;
+        }
+        for (; s < d.splitk; ++s) acc += d.ws[(long)s * total + i];
         const int bz = (int)(i / ((long)d.M * d.N));
         const long rem = i - (long)bz * d.M * d.N;
         const int m = (int)(rem / d.N), n = (int)(rem % d.N);
