@@ -10,6 +10,7 @@
 // into registers while the current one feeds the MFMAs (one barrier per chunk).
 #include "kernels.h"
 #include <cstdlib>
+#include <algorithm>
 
 namespace t2 {
 
@@ -586,19 +587,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmK g) {
 // operand bytes per MFMA of the converting kernel above and no conversion in the loop; two k-steps of 16-byte loads
 // (8 VGPRs each per operand) are kept in flight per wave.
 // ---------------------------------------------------------------------------------------------
-struct Raw16 { bf16x8 a[4], b[4]; unsigned ok; };
+// Block tile (32*TM*WM) x (32*TN*WN): WM x WN waves, each a TM x TN grid of 32x32 MFMA tiles; PF k-steps in flight.
+// Used as 128x128 (2x2 waves of 64x64), PF = 2: see the launch site for the other shapes that were measured.
+template <int NA, int NB> struct Raw16 { bf16x8 a[NA], b[NB]; unsigned ok; };
 // CONV_A: A16 is the bf16 copy of the frames X[M][C] and the operand is its implicit im2col (ConvAddr); C % 64 == 0, so
 // one 64-wide k-step lies inside one tap: the tile is the frame tile shifted by (tap - pad) rows, rows that leave
 // their utterance read as zero.  tpos[i] = (m0 + row_i) % T.
-template <bool CONV_A>
+template <bool CONV_A, int NT, int NA, int NB>
 __device__ __forceinline__ void issue16(const __bf16* __restrict__ A, long lda, const __bf16* __restrict__ B, long ldb, int k0,
-                                        ConvAddr cv, const int (&tpos)[4], Raw16& r) {
-    r.ok = 0xFu;
+                                        ConvAddr cv, const int (&tpos)[NA], Raw16<NA, NB>& r) {
+    r.ok = ~0u;
     int shift = 0, ka = k0;
     if constexpr (CONV_A) { const int dk = k0 / cv.C; ka = k0 - dk * cv.C; shift = dk - cv.pad; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = threadIdx.x + i * 256;
+    for (int i = 0; i < NA; ++i) {
+        const int q = threadIdx.x + i * NT;
         long row = q >> 3;
         if constexpr (CONV_A) {
             const bool ok = (unsigned)(tpos[i] + shift) < (unsigned)cv.T;
@@ -607,16 +610,16 @@ __device__ __forceinline__ void issue16(const __bf16* __restrict__ A, long lda, 
         r.a[i] = *reinterpret_cast<const bf16x8*>(A + row * lda + ka + (q & 7) * 8);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = threadIdx.x + i * 256;
+    for (int i = 0; i < NB; ++i) {
+        const int q = threadIdx.x + i * NT;
         r.b[i] = *reinterpret_cast<const bf16x8*>(B + (long)(q >> 3) * ldb + k0 + (q & 7) * 8);
     }
 }
-template <bool CONV_A>
-__device__ __forceinline__ void finish16(__bf16* __restrict__ as, __bf16* __restrict__ bs, const Raw16& r) {
+template <bool CONV_A, int NT, int NA, int NB>
+__device__ __forceinline__ void finish16(__bf16* __restrict__ as, __bf16* __restrict__ bs, const Raw16<NA, NB>& r) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = threadIdx.x + i * 256;
+    for (int i = 0; i < NA; ++i) {
+        const int q = threadIdx.x + i * NT;
         bf16x8 a = r.a[i];
         if constexpr (CONV_A) {
             if (!((r.ok >> i) & 1u)) {
@@ -625,39 +628,42 @@ __device__ __forceinline__ void finish16(__bf16* __restrict__ as, __bf16* __rest
             }
         }
         *reinterpret_cast<bf16x8*>(as + swz16(q >> 3, q & 7)) = a;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int q = threadIdx.x + i * NT;
         *reinterpret_cast<bf16x8*>(bs + swz16(q >> 3, q & 7)) = r.b[i];
     }
 }
 
-template <bool CONV_A>
-__global__ __launch_bounds__(256) void gemm_bf16src_kernel(GemmK g, const __bf16* __restrict__ A16, long lda, const __bf16* __restrict__ B16, long ldb) {
+template <bool CONV_A, int WM, int WN, int TM, int TN, int PF>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16src_kernel(GemmK g, const __bf16* __restrict__ A16, long lda, const __bf16* __restrict__ B16, long ldb) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN, NA = BM * 8 / NT, NB = BN * 8 / NT;
     const ConvAddr cva{g.d.conv_T, g.d.conv_C, g.d.conv_pad};
-    int tpos[4] = {0, 0, 0, 0};
+    int tpos[NA];
     const GemmDesc& d = g.d;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
     __bf16* const lds = reinterpret_cast<__bf16*>(smem16);
-    auto As = [&](int b) { return lds + b * (128 * PK16); };
-    auto Bs = [&](int b) { return lds + (2 + b) * (128 * PK16); };
+    auto As = [&](int b) { return lds + b * (BM * PK16); };
+    auto Bs = [&](int b) { return lds + 2 * (BM * PK16) + b * (BN * PK16); };
 
     const int split = blockIdx.z;
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kbeg = split * g.kchunks * BK, kend = min(d.K, kbeg + g.kchunks * BK);
     const __bf16* A = A16 + (long)m0 * lda;
     const __bf16* B = B16 + (long)n0 * ldb;
-    if constexpr (CONV_A) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) tpos[i] = (m0 + ((int)(threadIdx.x + i * 256) >> 3)) % cva.T;
-    }
+    for (int i = 0; i < NA; ++i) tpos[i] = CONV_A ? (m0 + ((int)(threadIdx.x + i * NT) >> 3)) % cva.T : 0;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -666,32 +672,47 @@ __global__ __launch_bounds__(256) void gemm_bf16src_kernel(GemmK g, const __bf16
         const __bf16* bs = Bs(buf);
 #pragma unroll
         for (int ks = 0; ks < BK16 / 16; ++ks) {
-            bf16x8 a[2], b[2];
+            bf16x8 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(as + swz16(wm * 64 + i * 32 + r, 2 * ks + h));
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(as + swz16(wm * (32 * TM) + i * 32 + r, 2 * ks + h));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bs + swz16(wn * 64 + j * 32 + r, 2 * ks + h));
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bs + swz16(wn * (32 * TN) + j * 32 + r, 2 * ks + h));
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     };
     const int nks = (kend - kbeg) / BK16;
-    if (nks > 0) {
-        Raw16 r0, r1;
-        issue16<CONV_A>(A, lda, B, ldb, kbeg, cva, tpos, r0);
-        if (nks > 1) issue16<CONV_A>(A, lda, B, ldb, kbeg + BK16, cva, tpos, r1);
-        finish16<CONV_A>(As(0), Bs(0), r0);
+    if constexpr (PF == 1) {                    // one k-step in flight (the 256x256 tile has no registers for two)
+        if (nks > 0) {
+            Raw16<NA, NB> r0;
+            issue16<CONV_A, NT>(A, lda, B, ldb, kbeg, cva, tpos, r0);
+            finish16<CONV_A, NT>(As(0), Bs(0), r0);
+            __syncthreads();
+            for (int ks = 0; ks < nks; ++ks) {
+                if (ks + 1 < nks) issue16<CONV_A, NT>(A, lda, B, ldb, kbeg + (ks + 1) * BK16, cva, tpos, r0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(ks & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 1 < nks) finish16<CONV_A, NT>(As((ks & 1) ^ 1), Bs((ks & 1) ^ 1), r0);
+                __syncthreads();
+            }
+        }
+    } else if (nks > 0) {
+        Raw16<NA, NB> r0, r1;
+        issue16<CONV_A, NT>(A, lda, B, ldb, kbeg, cva, tpos, r0);
+        if (nks > 1) issue16<CONV_A, NT>(A, lda, B, ldb, kbeg + BK16, cva, tpos, r1);
+        finish16<CONV_A, NT>(As(0), Bs(0), r0);
         __syncthreads();
         // invariant at the top of step ks: LDS buffer ks&1 holds k-step ks, `nxt` holds k-step ks+1 (in flight),
         // `free` is empty and receives k-step ks+2 before the MFMAs
-        auto step = [&](int ks, Raw16& nxt, Raw16& free_) {
-            if (ks + 2 < nks) issue16<CONV_A>(A, lda, B, ldb, kbeg + (ks + 2) * BK16, cva, tpos, free_);
+        auto step = [&](int ks, Raw16<NA, NB>& nxt, Raw16<NA, NB>& free_) {
+            if (ks + 2 < nks) issue16<CONV_A, NT>(A, lda, B, ldb, kbeg + (ks + 2) * BK16, cva, tpos, free_);
             __builtin_amdgcn_sched_barrier(0);
             mma(ks & 1);
             __builtin_amdgcn_sched_barrier(0);
-            if (ks + 1 < nks) finish16<CONV_A>(As((ks & 1) ^ 1), Bs((ks & 1) ^ 1), nxt);
+            if (ks + 1 < nks) finish16<CONV_A, NT>(As((ks & 1) ^ 1), Bs((ks & 1) ^ 1), nxt);
             __syncthreads();
         };
         int ks = 0;
@@ -703,17 +724,31 @@ __global__ __launch_bounds__(256) void gemm_bf16src_kernel(GemmK g, const __bf16
     float* C = d.C;
     float* ws = d.splitk > 1 ? d.ws + (long)split * (long)d.M * d.N : nullptr;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + r;
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (32 * TN) + j * 32 + r;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int m = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (ws) ws[(long)m * d.N + n] = acc[i][j][e];
                 else epilogue_store(d, C, m, n, acc[i][j][e], key);
             }
         }
+}
+
+template <bool CONV_A, int WM, int WN, int TM, int TN, int PF>
+int launch_bf16src(const GemmK& g, const __bf16* pa, long lda, const __bf16* pb, long ldb, int splitk, hipStream_t s) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    const size_t smem = (size_t)2 * (BM + BN) * PK16 * sizeof(__bf16);
+    static bool attr = false;
+    if (!attr) {
+        T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16src_kernel<CONV_A, WM, WN, TM, TN, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16src_kernel<CONV_A, WM, WN, TM, TN, PF>), dim3(g.d.N / BN, g.d.M / BM, splitk), dim3(64 * WM * WN), smem, s, g, pa, lda, pb, ldb);
+    T2_LAUNCH_CHECK();
+    return 0;
 }
 
 // staging casts: fp32 operand -> bf16 [rows][K] (K contiguous, leading dimension K)
@@ -893,15 +928,11 @@ int gemm(const GemmDesc& din, hipStream_t s) {
         }
         const __bf16* pa = d.A16 ? d.A16 : a16; const long lda = d.A16 ? d.lda16 : (d.conv_a ? d.conv_C : d.K);
         const __bf16* pb = d.B16 ? d.B16 : b16; const long ldb = d.B16 ? d.ldb16 : d.K;
-        const size_t smem = (size_t)4 * 128 * PK16 * sizeof(__bf16);
-        static bool attr16 = false;
-        if (!attr16) {
-            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16src_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16src_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            attr16 = true;
-        }
-        if (d.conv_a) hipLaunchKernelGGL(gemm_bf16src_kernel<true>, grid, dim3(256), smem, s, g, pa, lda, pb, ldb);
-        else hipLaunchKernelGGL(gemm_bf16src_kernel<false>, grid, dim3(256), smem, s, g, pa, lda, pb, ldb);
+        // 128x128 block tile, two k-steps in flight.  Measured alternatives (same template, other parameters): 256x128 with
+        // 8 waves 5-12 % slower, 256x256 with 128x64 wave tiles and one k-step in flight 4.6x slower (one workgroup per CU:
+        // nothing overlaps its barriers) — the kernel is bound by latency hiding, not by operand bytes per CU
+        if (d.conv_a) T2_TRY_RC((launch_bf16src<true, 2, 2, 2, 2, 2>(g, pa, lda, pb, ldb, splitk, s)));
+        else T2_TRY_RC((launch_bf16src<false, 2, 2, 2, 2, 2>(g, pa, lda, pb, ldb, splitk, s)));
     } else if (use_bf16) {
         const size_t smem = (size_t)4 * 128 * PK16 * sizeof(__bf16);
         static bool attr_set = false;
