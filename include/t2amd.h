@@ -56,6 +56,9 @@ int t2_set_overlap(int on);
  * bytes per MFMA; implicit-conv operands included).  0: always convert while staging through LDS.  Same rounding
  * of the operands either way; only the summation order inside a dot product differs. */
 int t2_set_gemm_staging(int on);
+/* Makes `stream` wait for everything the library has queued on its internal side stream of the current device
+ * (t2_decoder_bwd_args.defer_weight_grads). */
+int t2_side_join(void* stream);
 
 /* Model dimensions (hparams.py:55-95). */
 typedef struct t2_dims {
@@ -185,6 +188,10 @@ typedef struct t2_decoder_bwd_args {
     const float* ws;           /* workspace filled by t2_decoder_forward */
     float* bws;                /* t2_decoder_bwd_layout.total_floats floats of scratch */
     int training; int prenet_dropout; uint64_t seed;   /* must equal the forward call's */
+    int defer_weight_grads;    /* 1 (with t2_set_overlap on, T >= 32): d_memory / d_memory_sub are complete on `stream` when the
+                                * call returns, the weight gradients in `g` are still being written on the library's side
+                                * stream; call t2_side_join(stream) before reading them or releasing ws / bws.  0: everything
+                                * is ordered on `stream`. */
 } t2_decoder_bwd_args;
 int t2_decoder_backward(const t2_dims* dims, const t2_decoder_weights* w, const t2_decoder_grads* g,
                         const t2_decoder_bwd_args* a, void* stream);

@@ -101,7 +101,7 @@ class DecoderBwdArgs(C.Structure):
                 ("memory", C.c_void_p), ("memory_sub", C.c_void_p), ("align", C.c_void_p), ("align_sub", C.c_void_p),
                 ("d_mel", C.c_void_p), ("d_gate", C.c_void_p), ("d_align", C.c_void_p), ("d_align_sub", C.c_void_p),
                 ("d_memory", C.c_void_p), ("d_memory_sub", C.c_void_p), ("ws", C.c_void_p), ("bws", C.c_void_p),
-                ("training", C.c_int), ("prenet_dropout", C.c_int), ("seed", C.c_uint64)]
+                ("training", C.c_int), ("prenet_dropout", C.c_int), ("seed", C.c_uint64), ("defer_weight_grads", C.c_int)]
 
 
 class ConvBnArgs(C.Structure):
@@ -149,7 +149,7 @@ class GemmArgs(C.Structure):
 
 
 # every symbol include/t2amd.h declares (tests/test_abi.py checks the library exports them all)
-EXPORTS = ["t2_last_error", "t2_version", "t2_set_precision", "t2_get_precision", "t2_set_overlap", "t2_set_gemm_staging", "t2_decoder_layout_query", "t2_decoder_forward", "t2_decoder_infer",
+EXPORTS = ["t2_last_error", "t2_version", "t2_set_precision", "t2_get_precision", "t2_set_overlap", "t2_set_gemm_staging", "t2_side_join", "t2_decoder_layout_query", "t2_decoder_forward", "t2_decoder_infer",
            "t2_decoder_bwd_layout_query", "t2_decoder_backward", "t2_prof_enable", "t2_prof_collect", "t2_adam_chunks", "t2_adam_step",
            "t2_conv_bn_forward", "t2_conv_bn_backward", "t2_embedding_forward", "t2_embedding_backward",
            "t2_lstm_seq_forward", "t2_lstm_seq_backward", "t2_gemm_ex", "t2_colsum", "t2_mask_btc",

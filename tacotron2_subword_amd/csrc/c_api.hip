@@ -2,6 +2,7 @@
 // pass.  No device allocation, no synchronisation except where the header says so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/t2amd.h"
@@ -667,6 +668,15 @@ int t2_set_precision(int mode) {
 int t2_get_precision(void) { return get_precision(); }
 int t2_set_overlap(int on) { g_overlap = on != 0; return 0; }
 int t2_set_gemm_staging(int on) { set_gemm_staging(on); return 0; }
+int t2_side_join(void* stream) {
+    Side* side = nullptr;
+    T2_TRY(side_get(&side));
+    hipEvent_t e;
+    T2_TRY(side_event(*side, 0, &e));          // slot 0 is free between calls: every call re-records its events before use
+    T2_CHECK_HIP(hipEventRecord(e, side->s));
+    T2_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, e, 0));
+    return 0;
+}
 
 int t2_decoder_layout_query(const t2_dims* dims_in, int B, int T, int Tin, int Tsub, t2_decoder_layout* out) {
     T2_REQUIRE(dims_in && out, "null argument");
@@ -858,7 +868,18 @@ int t2_decoder_backward(const t2_dims* dims_in, const t2_decoder_weights* w, con
         }
         for (int t = t1 - 1; t >= t0; --t) T2_TRY(att_bwd_step(c, t));
     }
-    if (overlap) T2_TRY(stream_edge(*side, ne++, side->s, c.s));       // join (split-K scratch and colsum scratch are shared)
+    // ---- after the chains.  Only d(memory) feeds the caller's next backward nodes (the encoders); every weight gradient
+    // is a leaf.  defer_weight_grads: the weight-gradient tail (and the decoder-LSTM weight gradients already queued
+    // there) stays on the side stream, un-joined, underneath the encoders' backward — the caller joins with
+    // t2_side_join() before it reads a gradient or releases a workspace.  Otherwise: join here, one stream.
+    const bool defer = overlap && a->defer_weight_grads != 0;
+    hipStream_t ts = c.s;                                                // stream of the weight-gradient tail
+    if (defer) {
+        T2_TRY(stream_edge(*side, ne++, c.s, side->s));                 // chain A is complete: dG, dq, d(pm) of every step
+        ts = side->s;
+    } else if (overlap) {
+        T2_TRY(stream_edge(*side, ne++, side->s, c.s));                 // join (split-K scratch and colsum scratch are shared)
+    }
     for (int s = 0; s < z.NS; ++s) {
         const t2_lstm_weights& lw = s ? w->att_sub : w->att;
         const t2_lstm_grads& lg = s ? g->att_sub : g->att;
@@ -877,14 +898,14 @@ int t2_decoder_backward(const t2_dims* dims_in, const t2_decoder_weights* w, con
         const bool share = get_precision() == 1 && BT % 64 == 0 && z.B % 8 == 0 && (4 * z.Ha) % 128 == 0 && z.T > 1 &&
                            c.gemm_ws_bytes() >= 2 * dgt_bytes;
         __bf16* dgT = reinterpret_cast<__bf16*>(c.gemm_ws());
-        if (share) T2_TRY(stage_bf16(DG, false, 4 * z.Ha, dgT, 4 * z.Ha, BT, c.s));
+        if (share) T2_TRY(stage_bf16(DG, false, 4 * z.Ha, dgT, 4 * z.Ha, BT, ts));
         auto dw_gemm = [&](const float* G, long col0, const float* X, long ldx, float* Y, long ldy, int N, int K) -> int {
             GemmDesc m = matmul_tn(c, G, 4 * z.Ha, X, ldx, Y, ldy, 4 * z.Ha, N, K);
             if (share) {
                 m.A16 = dgT + col0; m.lda16 = BT;
                 m.ws = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(c.gemm_ws()) + dgt_bytes); m.ws_bytes = c.gemm_ws_bytes() - dgt_bytes;
             }
-            return gemm(m, c.s);
+            return gemm(m, ts);
         };
         T2_TRY(dw_gemm(DG, 0, P2, z.P, lg.w_ih, ldw, z.P, BT));
         if (z.T > 1) {
@@ -894,37 +915,37 @@ int t2_decoder_backward(const t2_dims* dims_in, const t2_decoder_weights* w, con
         } else {
             GemmDesc zc = matmul_tn(c, DG, 4 * z.Ha, DIN + coff, z.WD, lg.w_ih + z.P, ldw, 4 * z.Ha, z.E, BT);
             zc.alpha = 0.f;
-            T2_TRY(gemm(zc, c.s));
-            T2_TRY(fill_f32(lg.w_hh, 0.f, (size_t)4 * z.Ha * z.Ha, c.s));
+            T2_TRY(gemm(zc, ts));
+            T2_TRY(fill_f32(lg.w_hh, 0.f, (size_t)4 * z.Ha * z.Ha, ts));
         }
-        T2_TRY(colsum(DG, 4 * z.Ha, BT, 4 * z.Ha, lg.b_ih, lg.b_hh, cws, c.s));
+        T2_TRY(colsum(DG, 4 * z.Ha, BT, 4 * z.Ha, lg.b_ih, lg.b_hh, cws, ts));
         // prenet (model.py:13-24): dP2 = dG . W_ih[:, :P] ; through ReLU+dropout ; layer 2 ; layer 1
         const float scale = a->prenet_dropout ? 1.0f / (1.0f - dims->p_prenet_dropout) : 1.0f;
         GemmDesc gp = matmul_nn(DG, 4 * z.Ha, lw.w_ih, ldw, dP2, z.P, BT, z.P, 4 * z.Ha);
         gp.ws = c.gemm_ws(); gp.ws_bytes = c.gemm_ws_bytes();
-        T2_TRY(gemm(gp, c.s));
-        T2_TRY(relu_drop_bwd(dP2, P2, dP2, scale, (size_t)BT * z.P, c.s));
-        T2_TRY(gemm(matmul_tn(c, dP2, z.P, P1, z.P, s ? g->prenet_sub_w2 : g->prenet_w2, z.P, z.P, z.P, BT), c.s));
-        T2_TRY(gemm(matmul_nn(dP2, z.P, s ? w->prenet_sub_w2 : w->prenet_w2, z.P, dP1, z.P, BT, z.P, z.P), c.s));
-        T2_TRY(relu_drop_bwd(dP1, P1, dP1, scale, (size_t)BT * z.P, c.s));
-        T2_TRY(gemm(matmul_tn(c, dP1, z.P, c.W(L.x), z.M, s ? g->prenet_sub_w1 : g->prenet_w1, z.M, z.P, z.M, BT), c.s));
+        T2_TRY(gemm(gp, ts));
+        T2_TRY(relu_drop_bwd(dP2, P2, dP2, scale, (size_t)BT * z.P, ts));
+        T2_TRY(gemm(matmul_tn(c, dP2, z.P, P1, z.P, s ? g->prenet_sub_w2 : g->prenet_w2, z.P, z.P, z.P, BT), ts));
+        T2_TRY(gemm(matmul_nn(dP2, z.P, s ? w->prenet_sub_w2 : w->prenet_w2, z.P, dP1, z.P, BT, z.P, z.P), ts));
+        T2_TRY(relu_drop_bwd(dP1, P1, dP1, scale, (size_t)BT * z.P, ts));
+        T2_TRY(gemm(matmul_tn(c, dP1, z.P, c.W(L.x), z.M, s ? g->prenet_sub_w1 : g->prenet_w1, z.M, z.P, z.M, BT), ts));
         // attention parameters
         const int nsp = attn_bwd_nsplit(*dims, z);
         float* DQ = c.S(s ? BL.dqs : BL.dq);
-        if (nsp == 2) T2_TRY(fold_halves(DQ, BT, z.A, c.s));               // dq row = partial 0 + partial 1
-        T2_TRY(gemm(matmul_tn(c, DQ, 2 * z.A, DIN + hoff, z.WD, ag.wq, z.Ha, z.A, z.Ha, BT), c.s));
+        if (nsp == 2) T2_TRY(fold_halves(DQ, BT, z.A, ts));               // dq row = partial 0 + partial 1
+        T2_TRY(gemm(matmul_tn(c, DQ, 2 * z.A, DIN + hoff, z.WD, ag.wq, z.Ha, z.A, z.Ha, BT), ts));
         const bool dcak = dims->attention_kind == T2_ATTN_DCA;
         const bool gmm = dims->attention_kind == T2_ATTN_GMM || dcak;     // both: no processed-memory term
         if (dcak) {
             // W.weight went through the query-projection path above; W.bias = column sums of dq; the rest from the per-item
             // accumulators dv | dbT | dU | dT | dF | dV (attention.hip)
             T2_REQUIRE(ag.mlp_b1 && ag.mlp_w2 && ag.loc_conv && ag.loc_dense && ag.dca_T && ag.dca_bT && ag.v, "t2_decoder_backward: DCA gradient buffers missing");
-            T2_TRY(colsum(DQ, 2 * z.A, BT, z.A, ag.mlp_b1, nullptr, cws, c.s));
+            T2_TRY(colsum(DQ, 2 * z.A, BT, z.A, ag.mlp_b1, nullptr, cws, ts));
             const size_t na = dca_acc_floats(z.A);
             float* full = c.gemm_ws();                                   // [na] floats of the split-K scratch (idle here)
             T2_REQUIRE(na * sizeof(float) <= c.gemm_ws_bytes(), "t2_decoder_backward: scratch too small");
-            T2_TRY(batch_sum(c.S(s ? BL.dldenses : BL.dldense), z.B, (int)na, full, c.s));
-            auto cp = [&](float* dst, size_t off, size_t n) { return hipMemcpyAsync(dst, full + off, n * sizeof(float), hipMemcpyDeviceToDevice, c.s); };
+            T2_TRY(batch_sum(c.S(s ? BL.dldenses : BL.dldense), z.B, (int)na, full, ts));
+            auto cp = [&](float* dst, size_t off, size_t n) { return hipMemcpyAsync(dst, full + off, n * sizeof(float), hipMemcpyDeviceToDevice, ts); };
             size_t off = 0;
             T2_CHECK_HIP(cp(ag.v, off, z.A)); off += z.A;
             T2_CHECK_HIP(cp(ag.dca_bT, off, z.A)); off += z.A;
@@ -936,26 +957,26 @@ int t2_decoder_backward(const t2_dims* dims_in, const t2_decoder_weights* w, con
             // mlp.0.weight was handled as the query projection above; mlp.0.bias = column sums of dq; second layer from
             // the per-item accumulators; memory_layer takes no part in the arithmetic (its gradient is None in the reference)
             T2_REQUIRE(ag.mlp_b1 && ag.mlp_w2 && ag.mlp_b2, "t2_decoder_backward: GMM needs mlp_b1 / mlp_w2 / mlp_b2 gradient buffers");
-            T2_TRY(colsum(DQ, 2 * z.A, BT, z.A, ag.mlp_b1, nullptr, cws, c.s));
-            T2_TRY(batch_sum(c.S(s ? BL.dldenses : BL.dldense), z.B, 3 * kGmmK * z.A, ag.mlp_w2, c.s));
+            T2_TRY(colsum(DQ, 2 * z.A, BT, z.A, ag.mlp_b1, nullptr, cws, ts));
+            T2_TRY(batch_sum(c.S(s ? BL.dldenses : BL.dldense), z.B, 3 * kGmmK * z.A, ag.mlp_w2, ts));
             float* b2tmp = cws;                                          // 16 floats of scratch (slot 15 is padding)
-            T2_TRY(batch_sum(c.S(s ? BL.dlconvs : BL.dlconv), z.B, 16, b2tmp, c.s));
-            T2_CHECK_HIP(hipMemcpyAsync(ag.mlp_b2, b2tmp, 3 * kGmmK * sizeof(float), hipMemcpyDeviceToDevice, c.s));
+            T2_TRY(batch_sum(c.S(s ? BL.dlconvs : BL.dlconv), z.B, 16, b2tmp, ts));
+            T2_CHECK_HIP(hipMemcpyAsync(ag.mlp_b2, b2tmp, 3 * kGmmK * sizeof(float), hipMemcpyDeviceToDevice, ts));
         } else {
-            T2_TRY(batch_sum(c.S(s ? BL.dvs : BL.dv), nsp * z.B, z.A, ag.v, c.s));
+            T2_TRY(batch_sum(c.S(s ? BL.dvs : BL.dv), nsp * z.B, z.A, ag.v, ts));
         }
         if (dims->attention_kind == T2_ATTN_LSA) {
             T2_REQUIRE(ag.loc_conv && ag.loc_dense, "t2_decoder_backward: LSA needs loc_conv / loc_dense gradient buffers");
-            T2_TRY(batch_sum(c.S(s ? BL.dlconvs : BL.dlconv), z.B, dims->loc_filters * 2 * dims->loc_kernel, ag.loc_conv, c.s));
-            T2_TRY(batch_sum(c.S(s ? BL.dldenses : BL.dldense), z.B, z.A * dims->loc_filters, ag.loc_dense, c.s));
+            T2_TRY(batch_sum(c.S(s ? BL.dlconvs : BL.dlconv), z.B, dims->loc_filters * 2 * dims->loc_kernel, ag.loc_conv, ts));
+            T2_TRY(batch_sum(c.S(s ? BL.dldenses : BL.dldense), z.B, z.A * dims->loc_filters, ag.loc_dense, ts));
         }
         const float* mem = s ? a->memory_sub : a->memory;
         float* dmem = s ? a->d_memory_sub : a->d_memory;
         if (!gmm) {
             const float* DPM = c.S(s ? BL.dpms : BL.dpm);
-            T2_TRY(gemm(matmul_tn(c, DPM, z.A, mem, z.E, ag.wm, z.E, z.A, z.E, z.B * Tin), c.s));
+            T2_TRY(gemm(matmul_tn(c, DPM, z.A, mem, z.E, ag.wm, z.E, z.A, z.E, z.B * Tin), ts));
             // d(memory) = dPM . Wm  +  per item: align^T [Tin x T] . dctx [T x E]
-            T2_TRY(gemm(matmul_nn(DPM, z.A, aw.wm, z.E, dmem, z.E, z.B * Tin, z.E, z.A), c.s));
+            T2_TRY(gemm(matmul_nn(DPM, z.A, aw.wm, z.E, dmem, z.E, z.B * Tin, z.E, z.A), c.s));     // caller's stream: feeds the encoders
         }
         GemmDesc dm = gemm_desc();
         dm.A = s ? a->align_sub : a->align; dm.sam = 1; dm.sak = Tin; dm.bsA = (long)z.T * Tin;

@@ -80,6 +80,9 @@ def apply_gradient_allreduce(module):
     if getattr(module, "_t2_arena", None) is not None:
         return module                               # the reference wraps twice (train.py:81,219); hooks exist already
     world = dist.get_world_size()
+    dec = getattr(module, "decoder", None)
+    if dec is not None and hasattr(dec, "defer_weight_grads"):
+        dec.defer_weight_grads = False              # the hooks below read gradients during backward: no side-stream tail
     arena = GradArena(module)
     module._t2_arena = arena
     module.needs_reduction = False

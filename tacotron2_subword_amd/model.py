@@ -142,9 +142,21 @@ class _DecoderFn(torch.autograd.Function):
         memory, memory_sub = (ctx.saved_tensors + (None,))[:2]
         c = lambda g, ref: torch.zeros_like(ref) if g is None else g.contiguous()
         cz = lambda g: None if g is None else g.contiguous()
+        # Only d(memory) feeds further backward nodes (the encoders); the weight gradients are leaves.  With
+        # defer_weight_grads the library leaves them on its side stream underneath the encoders' backward, and the
+        # join is queued for the end of this backward pass (before anything reads .grad).
+        # (only when every decoder gradient slot is empty: AccumulateGrad then takes the new tensor without reading it;
+        # an accumulation into an existing .grad would read it on this stream too early)
+        dec = cfg["decoder"]
+        keep = [] if (getattr(dec, "defer_weight_grads", False) and all(p.grad is None for p in dec.parameters())) else None
         G, dm, dms = ops.decoder_backward(ctx.W, ctx.P, cfg["decoder"].dims, dp, memory, memory_sub, c(d_mel, dp.mel),
                                           c(d_gate, dp.gate), training=cfg["training"], prenet_dropout=cfg["prenet_dropout"],
-                                          seed=cfg["seed"], d_align=cz(d_align), d_align_sub=cz(d_align_sub))
+                                          seed=cfg["seed"], d_align=cz(d_align), d_align_sub=cz(d_align_sub), defer=keep)
+        if keep is not None:
+            def _join(keep=keep):
+                ops.side_join()
+                keep.clear()
+            torch.autograd.Variable._execution_engine.queue_callback(_join)
         grads = tuple(G.get("decoder." + k) for k in cfg["keys"])
         ctx.dp = None
         return (dm, dms, None, None, None, None) + grads
@@ -193,6 +205,7 @@ class Decoder(nn.Module):
         self.gate_layer = LinearNorm(Hd + ns * E, 1, bias=True, w_init_gain="sigmoid")
         self.dims = L.dims_from_hparams(hp, ns)
         self.prenet_dropout = True          # model.py:23 (always on); tests switch it off for deterministic parity
+        self.defer_weight_grads = False     # True: weight gradients finish on the library's side stream (see _DecoderFn); measured: +0.5 %
         self.base_seed, self._calls = int(getattr(hp, "seed", 1234)), 0
 
     # -- helpers ---------------------------------------------------------------------------

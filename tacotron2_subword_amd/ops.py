@@ -91,10 +91,18 @@ def decoder_prologue(W: L.DecoderWeights, dims: L.Dims, dp: DecoderPass, mels, *
     L.check(L.lib().t2_decoder_forward(C.byref(dims), C.byref(W), C.byref(a), L.stream()))
 
 
+def side_join() -> None:
+    """Make the current stream wait for the library's side stream (deferred weight gradients)."""
+    L.check(L.lib().t2_side_join(L.stream()))
+
+
 def decoder_backward(W: L.DecoderWeights, P: dict, dims: L.Dims, dp: DecoderPass, memory, memory_sub, d_mel, d_gate, *,
-                     training: bool, prenet_dropout: bool, seed: int, d_align=None, d_align_sub=None, prefix="decoder."):
+                     training: bool, prenet_dropout: bool, seed: int, d_align=None, d_align_sub=None, prefix="decoder.",
+                     defer: Optional[list] = None):
     """Backward of decoder_forward.  P: the (reference-keyed) weight dict, used for gradient shapes.
-    Returns (grads dict keyed like P, d_memory, d_memory_sub)."""
+    Returns (grads dict keyed like P, d_memory, d_memory_sub).  defer: a list -> the weight gradients are left on the
+    library's side stream (d_memory* are complete on the current stream); the tensors that stream still uses are appended
+    to the list and the caller must call side_join() before reading a gradient or dropping the list."""
     single = dims.n_streams == 1
     dev = memory.device
     G = {prefix + k: torch.empty_like(P[prefix + k]) for k in L.decoder_param_keys(dims.attention_kind, single)}
@@ -105,8 +113,10 @@ def decoder_backward(W: L.DecoderWeights, P: dict, dims: L.Dims, dp: DecoderPass
     d_mem_sub = None if single else torch.empty_like(memory_sub)
     a = L.DecoderBwdArgs(dp.B, dp.T, dp.Tin, dp.Tsub, L.ptr(memory), L.ptr(memory_sub), L.ptr(dp.align), L.ptr(dp.align_sub),
                          L.ptr(d_mel), L.ptr(d_gate), L.ptr(d_align), L.ptr(d_align_sub), L.ptr(d_mem), L.ptr(d_mem_sub),
-                         L.ptr(dp.ws), L.ptr(bws), int(training), int(prenet_dropout), seed)
+                         L.ptr(dp.ws), L.ptr(bws), int(training), int(prenet_dropout), seed, int(defer is not None))
     L.check(L.lib().t2_decoder_backward(C.byref(dims), C.byref(W), C.byref(GS), C.byref(a), L.stream()))
+    if defer is not None:
+        defer.extend([bws, dp, memory, memory_sub, d_mel, d_gate, d_align, d_align_sub])   # not G: AccumulateGrad must be able to steal it
     return G, d_mem, d_mem_sub
 
 

@@ -188,6 +188,35 @@ def test_training_mode_full_model_vs_oracle(att):
         assert maxabs(sd[k].float(), v.float()) < 1e-5, k
 
 
+def test_deferred_weight_gradients_and_prologue_are_bitwise_neutral():
+    """The stream-level schedule (decoder prologue under the encoders, weight-gradient tail of the decoder backward on
+    the library's side stream, joined at the end of backward — off by default) changes no arithmetic: every gradient is bit-identical
+    to the one-stream schedule, two iterations in a row (T = 40 takes the two-chain path)."""
+    from tacotron2_subword_amd.loss_function import Tacotron2Loss
+    hp = hp_for(SMA)
+    B, Tin, Tsub, T = 4, 21, 13, 40
+    m, hps = build_model(SMA, train=True)
+    m.decoder.prenet_dropout = True
+    batch = recipe.make_batch(hp, B, Tin, Tsub, T)
+    x, y = m.parse_batch(batch)
+    res = {}
+    for mode in (True, False):
+        m.overlap_encoders, m.decoder.defer_weight_grads = mode, mode
+        m._t2_calls, m.decoder._t2_calls = 0, 0
+        out = []
+        for it in range(2):
+            m.zero_grad()
+            loss = Tacotron2Loss()(m(x), y, x)[0]
+            loss.backward()
+            out.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        res[mode] = out
+    torch.cuda.synchronize()
+    for it in range(2):
+        assert res[True][it].keys() == res[False][it].keys()
+        for k in res[True][it]:
+            assert torch.equal(res[True][it][k], res[False][it][k]), (it, k)
+
+
 def test_bf16_operand_mode_stays_close_to_fp32_golden():
     """bf16-operand GEMMs (fp32 accumulate and state) are the throughput mode, not the parity mode: this
     records how far the outputs move on the BASELINE-shaped golden case (400 recurrent frames)."""
