@@ -28,10 +28,11 @@ def load(d, counter):
 
 def main():
     fd, wd, dst = sys.argv[1:4]
+    keep = tuple(sys.argv[4].split(",")) if len(sys.argv) > 4 else ("lstm", "attention", "step", "proj", "prenet")
     F, W = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
     res = {}
     for k in sorted(set(F) | set(W)):
-        if not any(t in k for t in ("lstm", "attention", "step", "proj", "prenet")):
+        if not any(t in k for t in keep):
             continue
         f = statistics.median(F.get(k, [0.0])); w = statistics.median(W.get(k, [0.0]))
         res[k] = {"launches": len(F.get(k, [])), "FETCH_SIZE_KB_median": f, "WRITE_SIZE_KB_median": w,
