@@ -51,6 +51,15 @@ int t2_get_precision(void);
 /* 1 (default): teacher-forced passes run the decoder-LSTM chain on an internal side stream, one chunk of steps
  * apart from the attention chain (fork/join inside the call; the caller's stream semantics are unchanged).  0: one stream. */
 int t2_set_overlap(int on);
+/* Persistent chain kernels (csrc/chain.hip), bf16 mode, default dims, B <= 128, SMA: 1 (default; env T2_CHAIN=0 turns it
+ * off) runs ALL steps of the attention chain (both attention LSTMs + attention; model.py:322-369) and of the decoder-LSTM
+ * chain (model.py:371-373) of a teacher-forced pass in one launch each, with the recurrent weights resident in registers
+ * and h / ctx / query partials exchanged between workgroups through write-through stores and arrival counters.  They need
+ * the whole device (256 co-resident workgroups): ONE process per GPU, as the reference runs (distributed.py:181-200).
+ * A chain that could not make progress for 1 s gives up and leaves a non-zero status word in the workspace
+ * (t2_decoder_layout.chain); 0: one launch per step and kernel, as in round 1. */
+int t2_set_chain(int on);
+int t2_get_chain(void);
 /* bf16 mode only.  1 (default): a large GEMM whose extents are whole 128x128x64 tiles first writes bf16 copies of its
  * fp32 operands (K contiguous) into the caller's scratch and runs the bf16-source kernel on them (half the operand
  * bytes per MFMA; implicit-conv operands included).  0: always convert while staging through LDS.  Same rounding
@@ -127,6 +136,9 @@ typedef struct t2_decoder_layout {
      * decoder W_hh, their transposes for the backward pass, and bf16 copies of DIN / dec_h */
     size_t w16a, w16as, w16d, wt16a, wt16as, wt16d, din16, dh16;
     size_t gemm_ws; size_t gemm_ws_floats;
+    size_t chain; size_t chain_floats;   /* exchange buffers of the persistent chain kernels (t2_set_chain): word 0 = status of
+                                          * the attention chain, word 1 = status of the decoder-LSTM chain (0 = OK), then arrival
+                                          * counters, fragment-ordered h / ctx buffers, query partials */
 } t2_decoder_layout;
 
 int t2_decoder_layout_query(const t2_dims* dims, int B, int T, int Tin, int Tsub, t2_decoder_layout* out);

@@ -49,7 +49,7 @@ class DecoderWeights(C.Structure):
 _LAYOUT_FIELDS = ["total_floats", "x", "p1", "p2", "p1s", "p2s", "pm", "pms", "prea", "preas", "ga", "gas",
                   "cna", "cnas", "ca", "cas", "din", "psel", "psels", "wcum", "wcums", "pred", "gd", "cnd", "cd",
                   "dout", "qs", "qss", "qpart", "w1t", "w16a", "w16as", "w16d", "wt16a", "wt16as", "wt16d", "din16", "dh16",
-                  "gemm_ws", "gemm_ws_floats"]
+                  "gemm_ws", "gemm_ws_floats", "chain", "chain_floats"]
 
 
 class DecoderLayout(C.Structure):
@@ -149,7 +149,7 @@ class GemmArgs(C.Structure):
 
 
 # every symbol include/t2amd.h declares (tests/test_abi.py checks the library exports them all)
-EXPORTS = ["t2_last_error", "t2_version", "t2_set_precision", "t2_get_precision", "t2_set_overlap", "t2_set_gemm_staging", "t2_side_join", "t2_decoder_layout_query", "t2_decoder_forward", "t2_decoder_infer",
+EXPORTS = ["t2_last_error", "t2_version", "t2_set_precision", "t2_get_precision", "t2_set_overlap", "t2_set_chain", "t2_get_chain", "t2_set_gemm_staging", "t2_side_join", "t2_decoder_layout_query", "t2_decoder_forward", "t2_decoder_infer",
            "t2_decoder_bwd_layout_query", "t2_decoder_backward", "t2_prof_enable", "t2_prof_collect", "t2_adam_chunks", "t2_adam_step",
            "t2_conv_bn_forward", "t2_conv_bn_backward", "t2_embedding_forward", "t2_embedding_backward",
            "t2_lstm_seq_forward", "t2_lstm_seq_backward", "t2_gemm_ex", "t2_colsum", "t2_mask_btc",
@@ -361,7 +361,7 @@ def decoder_layout(dims: Dims, B: int, T: int, Tin: int, Tsub: int) -> DecoderLa
 
 
 PROF_KINDS = ["att_lstm_fwd", "attention_fwd", "dec_lstm_fwd", "attention_bwd", "att_lstm_bwd_pointwise",
-              "att_lstm_bwd_gemm", "dec_lstm_bwd_pointwise", "dec_lstm_bwd_gemm"]
+              "att_lstm_bwd_gemm", "dec_lstm_bwd_pointwise", "dec_lstm_bwd_gemm", "chain_a_fwd", "chain_b_fwd"]
 
 
 def prof_enable(max_launches: int) -> None:
@@ -374,6 +374,15 @@ def prof_collect() -> dict:
     ms, cnt = (C.c_double * n)(), (C.c_int * n)()
     check(lib().t2_prof_collect(n, ms, cnt))
     return {k: (ms[i], cnt[i]) for i, k in enumerate(PROF_KINDS)}
+
+
+def set_chain(on: bool) -> None:
+    """Persistent chain kernels for teacher-forced passes (include/t2amd.h: t2_set_chain)."""
+    check(lib().t2_set_chain(int(bool(on))))
+
+
+def get_chain() -> bool:
+    return bool(lib().t2_get_chain())
 
 
 def set_precision(mode: str) -> None:

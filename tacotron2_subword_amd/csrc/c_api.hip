@@ -33,7 +33,7 @@ using namespace t2;
 // the per-step kernel launches with HIP events on the launch stream.  Off by default.
 // ---------------------------------------------------------------------------------------------
 enum ProfKind { PK_LSTM_ATT_FWD = 0, PK_ATTN_FWD, PK_LSTM_DEC_FWD, PK_ATTN_BWD, PK_LSTM_ATT_BWD_PW, PK_LSTM_ATT_BWD_GEMM,
-                PK_LSTM_DEC_BWD_PW, PK_LSTM_DEC_BWD_GEMM, PK_COUNT };
+                PK_LSTM_DEC_BWD_PW, PK_LSTM_DEC_BWD_GEMM, PK_CHAIN_A_FWD, PK_CHAIN_B_FWD, PK_COUNT };
 struct Prof {
     bool on = false;
     std::vector<hipEvent_t> ev;
@@ -62,6 +62,7 @@ struct ProfScope {
 struct Side { hipStream_t s = nullptr; std::vector<hipEvent_t> ev; };
 static Side g_side[16];
 static int g_overlap = 1;
+static int g_chain = getenv("T2_CHAIN") ? atoi(getenv("T2_CHAIN")) : 1;   // persistent chain kernels (chain.hip)
 static int side_get(Side** out) {
     int dev = 0;
     T2_CHECK_HIP(hipGetDevice(&dev));
@@ -165,6 +166,30 @@ InferShadows infer_shadows(const Sizes& z, size_t base) {
     return m;
 }
 
+// Persistent chains: [status word | counters A | counters B | X of chain A | X of chain B | Q], each part 256-byte aligned.
+// Sized for the largest tiling chain_plan can choose at this batch size.
+struct ChainBufs { unsigned* err; unsigned* cnt_a; unsigned* cnt_b; unsigned char* xa; unsigned char* xb; float* q; size_t xa_bytes, xb_bytes, q_bytes; };
+size_t chain_part_bytes(const Sizes& z, size_t* xa, size_t* xb, size_t* q) {
+    const size_t MT = (z.B + 31) / 32;
+    *xa = (size_t)2 * z.NS * ((z.Ha + z.E) / 16) * MT * 1024;
+    *xb = (size_t)2 * (z.Hd / 16) * MT * 1024;
+    *q = (size_t)z.NS * MT * 32 * (z.Ha / 8) * z.A * sizeof(float);
+    return 256 + 2 * kChainCntBytes + *xa + *xb + *q;
+}
+size_t chain_region_bytes(const Sizes& z) { size_t a, b, q; return (chain_part_bytes(z, &a, &b, &q) + 255) & ~(size_t)255; }
+ChainBufs chain_bufs(const Sizes& z, const t2_decoder_layout& L, float* ws) {
+    ChainBufs b{};
+    chain_part_bytes(z, &b.xa_bytes, &b.xb_bytes, &b.q_bytes);
+    unsigned char* p = reinterpret_cast<unsigned char*>(ws + L.chain);
+    b.err = reinterpret_cast<unsigned*>(p); p += 256;
+    b.cnt_a = reinterpret_cast<unsigned*>(p); p += kChainCntBytes;
+    b.cnt_b = reinterpret_cast<unsigned*>(p); p += kChainCntBytes;
+    b.xa = p; p += b.xa_bytes;
+    b.xb = p; p += b.xb_bytes;
+    b.q = reinterpret_cast<float*>(p);
+    return b;
+}
+
 void layout_of(const t2_dims& d, const Sizes& z, t2_decoder_layout* L) {
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += align4(n); return o; };
@@ -194,6 +219,9 @@ void layout_of(const t2_dims& d, const Sizes& z, t2_decoder_layout* L) {
     L->din16 = take(BT * z.WD / 2 + 4); L->dh16 = take(BT * z.Hd / 2 + 4);
     L->gemm_ws_floats = (size_t)16 << 20;                     // 64 MiB of split-K scratch
     L->gemm_ws = take(L->gemm_ws_floats);
+    // exchange buffers of the persistent chain kernels (chain.hip), see chain_bufs()
+    L->chain_floats = chain_region_bytes(z) / sizeof(float);
+    L->chain = take(L->chain_floats);
     L->total_floats = off;
 }
 
@@ -405,6 +433,69 @@ int dec_lstm_step(const Dec& c, int t) {
     hipStream_t sd = c.sd ? c.sd : c.s;
     ProfScope ps(PK_LSTM_DEC_FWD, sd);
     return lstm_step_fwd(d, sd);
+}
+
+// Persistent-kernel descriptors of the two teacher-forced chains (chain.hip).  Returns false when the shape, mode or
+// device is not covered: the caller then launches the per-step kernels.
+bool chain_a_desc(const Dec& c, ChainDesc* out) {
+    const Sizes& z = c.z; const t2_decoder_layout& L = c.L;
+    if (!c.use16 || !c.teacher) return false;
+    if (c.d.attention_kind != T2_ATTN_SMA && c.d.attention_kind != T2_ATTN_LSA) return false;
+    ChainDesc d{};
+    d.NS = z.NS; d.B = z.B; d.T = z.T; d.H = z.Ha; d.E = z.E; d.A = z.A; d.WD = z.WD; d.WO = z.WO;
+    d.din = c.P(L.din); d.din16 = c.P16(L.din16); d.dout = c.P(L.dout);
+    d.kind = c.d.attention_kind == T2_ATTN_SMA ? CHAIN_SMA : CHAIN_LSA;
+    d.F = c.d.loc_filters; d.Kc = c.d.loc_kernel; d.max_pos = c.max_pos; d.mask_value = -INFINITY;
+    d.drop_p = c.training ? c.d.p_att_dropout : 0.f;
+    d.noise_std = (c.training && d.kind == CHAIN_SMA) ? 2.0f : 0.f;
+    d.seed = c.seed;
+    for (int s = 0; s < z.NS; ++s) {
+        ChainStream& st = d.st[s];
+        const t2_attention_weights& aw = s ? c.w.attn_sub : c.w.attn;
+        const int hoff = s ? z.Ha + z.E : 0;
+        st.w16 = c.P16(s ? L.w16as : L.w16a); st.ldw16 = z.Ha + z.E;
+        st.pre = c.P(s ? L.preas : L.prea); st.wq = aw.wq;
+        st.gates = c.P(s ? L.gas : L.ga); st.c_new = c.P(s ? L.cnas : L.cna); st.c_out = c.P(s ? L.cas : L.ca);
+        st.h_out = c.P(L.din) + hoff; st.ldh = z.WD; st.h16_out = c.P16(L.din16) + hoff; st.ldh16 = z.WD;
+        st.coff = hoff + z.Ha; st.ctx2off = z.Hd + (s ? z.E : 0);
+        st.pm = c.P(s ? L.pms : L.pm); st.memory = s ? c.memory_sub : c.memory; st.lengths = s ? c.len_sub : c.len;
+        st.Tin = s ? z.Tsub : z.Tin;
+        st.align = s ? c.align_sub : c.align; st.psel = c.P(s ? L.psels : L.psel); st.wcum = c.P(s ? L.wcums : L.wcum);
+        st.qs = c.P(s ? L.qss : L.qs);
+        st.v = aw.v; st.loc_conv = aw.loc_conv; st.loc_dense = aw.loc_dense;
+        st.site_h = s ? T2_SITE_ATT_H_SUB : T2_SITE_ATT_H; st.site_c = s ? T2_SITE_ATT_C_SUB : T2_SITE_ATT_C;
+        st.site_noise = s ? T2_SITE_NOISE_SUB : T2_SITE_NOISE;
+    }
+    if (!chain_plan(d)) return false;
+    const ChainBufs b = chain_bufs(z, L, c.ws);
+    size_t xb = 0, qb = 0;
+    chain_exchange_bytes(d, &xb, &qb);
+    if (xb > b.xa_bytes || qb > b.q_bytes) return false;
+    d.X = b.xa; d.Q = b.q; d.cnt = b.cnt_a; d.err = b.err; d.q_bytes = (unsigned)qb;
+    *out = d;
+    return true;
+}
+bool chain_b_desc(const Dec& c, ChainDesc* out) {
+    const Sizes& z = c.z; const t2_decoder_layout& L = c.L;
+    if (!c.use16 || !c.teacher) return false;
+    ChainDesc d{};
+    d.NS = 1; d.B = z.B; d.T = z.T; d.H = z.Hd; d.E = 0; d.A = 0; d.WD = z.WD; d.WO = z.WO;
+    d.kind = CHAIN_LSTM;
+    d.drop_p = c.training ? c.d.p_dec_dropout : 0.f;
+    d.seed = c.seed;
+    ChainStream& st = d.st[0];
+    st.w16 = c.P16(L.w16d); st.ldw16 = z.Hd; st.pre = c.P(L.pred);
+    st.gates = c.P(L.gd); st.c_new = c.P(L.cnd); st.c_out = c.P(L.cd);
+    st.h_out = c.P(L.dout); st.ldh = z.WO; st.h16_out = c.P16(L.dh16); st.ldh16 = z.Hd;
+    st.site_h = T2_SITE_DEC_H; st.site_c = T2_SITE_DEC_C; st.Tin = 4;
+    if (!chain_plan(d)) return false;
+    const ChainBufs b = chain_bufs(z, L, c.ws);
+    size_t xb = 0, qb = 0;
+    chain_exchange_bytes(d, &xb, &qb);
+    if (xb > b.xb_bytes) return false;
+    d.X = b.xb; d.Q = nullptr; d.cnt = b.cnt_b; d.err = b.err + 1; d.q_bytes = 0;
+    *out = d;
+    return true;
 }
 
 // mel / gate projection (model.py:382-388); permute_tb: rows come time-major, outputs are [B,T,*]
@@ -667,6 +758,8 @@ int t2_set_precision(int mode) {
 }
 int t2_get_precision(void) { return get_precision(); }
 int t2_set_overlap(int on) { g_overlap = on != 0; return 0; }
+int t2_set_chain(int on) { g_chain = on != 0; return 0; }
+int t2_get_chain(void) { return g_chain; }
 int t2_set_gemm_staging(int on) { set_gemm_staging(on); return 0; }
 int t2_side_join(void* stream) {
     Side* side = nullptr;
@@ -737,16 +830,31 @@ int t2_decoder_forward(const t2_dims* dims_in, const t2_decoder_weights* w, cons
     //   A (caller's stream): attention LSTMs + attention — the only truly recurrent chain through the contexts
     //   B (side stream):     hoisted input half of the decoder LSTM for the chunk A just finished
     //                        ([att_h|ctx|att_h_sub|ctx_sub] . W_ih^T + b), then the decoder-LSTM recurrence over it
+    // Persistent chains (chain.hip): every step of a chain in ONE launch, weights resident on chip.  Two persistent
+    // grids must never be in flight together (each needs the whole device to make progress), so with them the chains
+    // run back to back on the caller's stream: A over all steps, one input GEMM, B over all steps.
+    ChainDesc ca{}, cb{};
+    const bool chain_a = g_chain && chain_a_desc(c, &ca), chain_b = g_chain && chain_b_desc(c, &cb);
+    {   // status words always (0 = OK / not used); counters and the zero state of step -1 when a chain runs
+        const ChainBufs bufs = chain_bufs(z, L, a->ws);
+        T2_CHECK_HIP(hipMemsetAsync(bufs.err, 0, (chain_a || chain_b) ? 256 + 2 * kChainCntBytes + bufs.xa_bytes + bufs.xb_bytes : 256, c.s));
+    }
     Side* side = nullptr;
-    const bool overlap = g_overlap && z.T >= 32;
+    const bool overlap = g_overlap && z.T >= 32 && !chain_a && !chain_b;
     if (overlap) { T2_TRY(side_get(&side)); c.sd = side->s; }
     const std::vector<int> bounds = chunk_bounds(z.T, overlap);
     size_t ne = 0;
     for (size_t ci = 0; ci + 1 < bounds.size(); ++ci) {
         const int t0 = bounds[ci], t1 = bounds[ci + 1];
-        for (int t = t0; t < t1; ++t) {
-            T2_TRY(att_lstm_step(c, t));
-            T2_TRY(attention_step(c, t));
+        if (chain_a) {
+            ca.t0 = t0; ca.t1 = t1;
+            ProfScope ps(PK_CHAIN_A_FWD, c.s);
+            T2_TRY(chain_fwd(ca, c.s));
+        } else {
+            for (int t = t0; t < t1; ++t) {
+                T2_TRY(att_lstm_step(c, t));
+                T2_TRY(attention_step(c, t));
+            }
         }
         hipStream_t sb = overlap ? side->s : c.s;
         if (overlap) T2_TRY(stream_edge(*side, ne++, c.s, sb));
@@ -760,7 +868,13 @@ int t2_decoder_forward(const t2_dims* dims_in, const t2_decoder_weights* w, cons
             g.ws = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(g.ws) + w16_bytes); g.ws_bytes -= w16_bytes;
         }
         T2_TRY(gemm(g, sb));
-        for (int t = t0; t < t1; ++t) T2_TRY(dec_lstm_step(c, t));
+        if (chain_b) {
+            cb.t0 = t0; cb.t1 = t1;
+            ProfScope ps(PK_CHAIN_B_FWD, sb);
+            T2_TRY(chain_fwd(cb, sb));
+        } else {
+            for (int t = t0; t < t1; ++t) T2_TRY(dec_lstm_step(c, t));
+        }
     }
     if (overlap) T2_TRY(stream_edge(*side, ne++, side->s, c.s));         // join
     // projections over all frames

@@ -1,0 +1,569 @@
+// Persistent decoder-chain kernel: many consecutive time steps of the teacher-forced recurrences in ONE launch.
+//
+//   chain A (model.py:322-369, attention.py:7-85,291-398): both attention LSTMs + attention (SMA or LSA)
+//   chain B (model.py:371-373):                            the decoder LSTM over hoisted input pre-activations
+//
+// Why: as separate launches every step re-fetched its recurrent weights (25 MB of bf16 for chain A) and each launch
+// spent 5-9 us receiving operands through one CU (profiles/README.md, round 1).  Here a workgroup keeps ITS slice of
+// the recurrent weights in registers for all steps (256 workgroups x 96 KB = the whole [W_hh | W_ih[:,P:]] of both
+// attention LSTMs), its cell state in registers, its attention state (previous alignment, cumulative weights) and as
+// much of its item's processed memory / encoder memory as fits in LDS.  What crosses workgroups per step is only
+//   h_t   (bf16, MFMA-fragment order)        units -> every workgroup of the same stream and row group
+//   q_t   (fp32 partial query projections)   units -> the item's attention workgroups
+//   ctx_t (bf16, MFMA-fragment order)        items -> every LSTM workgroup of the same stream and row group
+// exchanged through L2-bypassing write-through stores (sc1), one arrival counter per (stream, row group, kind) and
+// sc1 loads on the consumer side (MI355X_MICROARCH.md "Valid forms": every payload store sc1 and drained by every
+// storing wave before the workgroup barrier, one lane signals with an agent-scope atomic, one wave polls with
+// relaxed agent loads, the other waves load behind the workgroup barrier, every payload load sc1).
+// scripts/persist_probe.hip measures this exact traffic pattern: ~3.4 us per all-to-all hop, two hops per step.
+//
+// Work items (one workgroup of 512 threads per CU, grid = 256):
+//   L item (s, ug, rg): stream s, unit group ug (8*UT hidden units = 32*UT gate columns), row group rg (32*RT batch rows).
+//       gates[32*RT x 32*UT] = pre[t] + [h_{t-1} | ctx_{t-1}] . W^T : the 8 waves split K, operands straight from the
+//       fragment-ordered exchange buffer into MFMA registers (one coalesced 1 KB load per fragment), partial tiles summed
+//       through LDS in fixed order, gates / cell / dropout per (row, unit), h_t published, fp32 query partial via
+//       v_mfma_f32_32x32x2_f32 on the fp32 h_t.
+//   A item (b, s, part): batch item b, stream s, 1/CS of the context columns.  Every part recomputes the (cheap)
+//       energies / alignment so that no exchange is needed inside an item; each part sums its own context columns.
+// Numerics = the launch-per-step bf16 path (lstm.hip / attention.hip) up to summation order, except: the energy tanh
+// and the SMA sigmoid use the hardware exp (abs. error ~1e-7), and context rows resident in LDS are bf16 copies of the
+// memory (every consumer of ctx in bf16 mode rounds it to bf16 anyway).
+#include <algorithm>
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace t2 {
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define T2_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+constexpr int NTH = 512, NWV = 8;
+constexpr int SC1 = 16;                    // buffer-instruction cache policy bit: sc1 (agent scope, bypass L1 / write through)
+constexpr int PPR = 40;                    // LDS pitch of a 32-wide partial tile row (conflict-free fixed-order reads)
+constexpr int CNT_STRIDE = 32;             // one arrival counter per 128-byte line
+constexpr unsigned long long SPIN_TICKS = 100000000ull;   // 1 s of the 100 MHz realtime counter: every spin is bounded
+
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - __fdividef(2.0f, __expf(2.0f * x) + 1.0f); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return __fdividef(1.0f, 1.0f + __expf(-x)); }
+
+// one wave polls one counter; all lanes read the same word (a single request), so the branch is wave-uniform
+__device__ __forceinline__ bool poll_counter(const unsigned* cnt, unsigned want, unsigned* err, unsigned code) {
+    if (want == 0) return true;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        const unsigned v = __hip_atomic_load(cnt, T2_RLX_AGENT);
+        if (v >= want) return true;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_TICKS) {
+            if ((threadIdx.x & 63) == 0) atomicMax(err, code);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+// after the payload stores of every wave: drain (every storing wave), workgroup barrier, one lane signals
+__device__ __forceinline__ void publish(unsigned* cnt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, T2_RLX_AGENT);
+}
+
+struct Geo {                                // derived on both sides from the descriptor
+    int MT, NRG, NUG, nL, nA, KT; unsigned xs_bytes;
+};
+__host__ __device__ inline Geo geo_of(const ChainDesc& d, int UT, int RT) {
+    Geo g;
+    g.MT = (d.B + 31) / 32; g.NRG = (g.MT + RT - 1) / RT; g.NUG = d.H / (8 * UT);
+    g.nL = d.NS * g.NUG * g.NRG; g.nA = d.kind == CHAIN_LSTM ? 0 : d.NS * d.B * d.CS;
+    g.KT = (d.H + (d.kind == CHAIN_LSTM ? 0 : d.E)) / 16;
+    g.xs_bytes = (unsigned)g.KT * g.MT * 1024u;
+    return g;
+}
+
+// LDS carve (floats).  Persistent part first, then a scratch area shared by the two phases.
+struct Lds { int ab, v, ap, cum, q, e, an, cs, pm, mem, scratch, total; };
+__host__ __device__ inline Lds lds_of(const ChainDesc& d, int UT, int RT, int Tin, int Jp, int Jm) {
+    Lds m; int o = 0;
+    auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+    const int Tp = (Tin + 3) & ~3, EC = d.kind == CHAIN_LSTM ? 0 : d.E / d.CS;
+    m.ab = take(4);
+    if (d.kind != CHAIN_LSTM) {
+        m.v = take(d.A); m.ap = take(Tp + 4); m.cum = take(Tp + 4); m.q = take(d.A); m.e = take(Tp + 4); m.an = take(Tp + 4); m.cs = take(EC);
+        m.pm = take(Jp * d.A); m.mem = take(Jm * EC / 2);
+    } else { m.v = m.ap = m.cum = m.q = m.e = m.an = m.cs = m.pm = m.mem = o; }
+    const int lpart = NWV * 32 * PPR, lhs = RT * 32 * (UT * 8 + 4), lq = d.kind == CHAIN_LSTM ? 0 : RT * 32 * (d.A + 4);
+    const int lphase = (lpart > lq ? lpart : lq) + lhs;
+    const int aphase = d.kind == CHAIN_LSTM ? 0 : 16 * d.A + NWV * EC;
+    m.scratch = take(lphase > aphase ? lphase : aphase);
+    m.total = o;
+    return m;
+}
+
+template <int UT, int RT, int KH, int KC, int KIND>
+__global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
+    constexpr int NTILE = UT * RT, NSLOT = (NTILE + 1) / 2, HSP = UT * 8 + 4;
+    const Geo G = geo_of(d, UT, RT);
+    const int wg = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hk = lane >> 5;
+    const int B = d.B, H = d.H, A = d.A;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    // ---------------------------------------------------------------- items of this workgroup
+    const bool hasL = wg < G.nL, hasA = KIND != CHAIN_LSTM && wg < G.nA;
+    int ls = 0, ug = 0, rg = 0;
+    if (hasL) { ls = wg / (G.NUG * G.NRG); const int rem = wg % (G.NUG * G.NRG); ug = rem / G.NRG; rg = rem % G.NRG; }
+    int as = 0, ab_ = 0, part = 0;
+    if (hasA) { as = wg / (B * d.CS); const int rem = wg % (B * d.CS); ab_ = rem / d.CS; part = rem % d.CS; }
+    const ChainStream& LS = d.st[ls];
+    const ChainStream& AS = d.st[as];
+    const int u0 = ug * 8 * UT, row0 = rg * 32 * RT;
+    const int arg = ab_ / (32 * RT), arow = ab_ % (32 * RT);         // row group / local row of the A item
+    const int EC = KIND == CHAIN_LSTM ? 0 : d.E / d.CS, c0 = part * EC;
+    const int Tin = hasA ? AS.Tin : 4, Tp = (Tin + 3) & ~3;
+    const int Jp = hasA ? (as ? d.Jp[1] : d.Jp[0]) : 0, Jm = hasA ? (as ? d.Jm[1] : d.Jm[0]) : 0;
+    const Lds M = lds_of(d, UT, RT, d.lds_Tin, d.lds_Jp, d.lds_Jm);   // one carve for every workgroup (largest stream)
+    unsigned* abortw = reinterpret_cast<unsigned*>(smem + M.ab);
+    float* vL = smem + M.v; float* apL = smem + M.ap; float* cumL = smem + M.cum; float* qL = smem + M.q;
+    float* eL = smem + M.e; float* anL = smem + M.an; float* csL = smem + M.cs;
+    float* pmL = smem + M.pm; __bf16* memL = reinterpret_cast<__bf16*>(smem + M.mem);
+    float* partL = smem + M.scratch;                                   // [NWV][32][PPR]      (L phase)
+    float* qsL = smem + M.scratch;                                     // [RT*32][A+4]        (L phase, after the reduce)
+    const int lq = KIND == CHAIN_LSTM ? 0 : RT * 32 * (A + 4);
+    float* hsL = smem + M.scratch + (NWV * 32 * PPR > lq ? NWV * 32 * PPR : lq);   // [RT*32][HSP]
+    float* redL = smem + M.scratch;                                    // [16][A]             (A phase)
+    float* credL = smem + M.scratch + 16 * A;                          // [NWV][EC]
+    (void)cumL; (void)qsL; (void)redL; (void)credL; (void)csL; (void)eL; (void)anL; (void)qL; (void)vL; (void)pmL; (void)memL;
+
+    auto rsX = __builtin_amdgcn_make_buffer_rsrc(d.X, 0, (int)(2u * d.NS * G.xs_bytes), 0x00020000);
+    auto rsQ = __builtin_amdgcn_make_buffer_rsrc(d.Q, 0, (int)d.q_bytes, 0x00020000);
+    unsigned* cntH_L = d.cnt + (size_t)((ls * G.NRG + rg) * 2 + 0) * CNT_STRIDE;
+    unsigned* cntC_L = d.cnt + (size_t)((ls * G.NRG + rg) * 2 + 1) * CNT_STRIDE;
+    unsigned* cntH_A = d.cnt + (size_t)((as * G.NRG + arg) * 2 + 0) * CNT_STRIDE;
+    unsigned* cntC_A = d.cnt + (size_t)((as * G.NRG + arg) * 2 + 1) * CNT_STRIDE;
+    const unsigned rows_in_rg = (unsigned)min(32 * RT, B - row0);      // valid rows of the L item's row group
+    const unsigned nA_per_step = rows_in_rg * (unsigned)d.CS;
+
+    if (tid == 0) *abortw = 0;
+
+    // ---------------------------------------------------------------- L setup: weight slice -> registers (once)
+    bf16x8 W[UT][KH + KC];
+    float wqf[UT * 4];
+    float cst[NSLOT];
+    if (hasL) {
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+            for (int i = 0; i < KH + KC; ++i) {
+                const int kt = i < KH ? wave * KH + i : H / 16 + wave * KC + (i - KH);
+                const long row = (long)(r >> 3) * H + u0 + ut * 8 + (r & 7);
+                W[ut][i] = *reinterpret_cast<const bf16x8*>(LS.w16 + row * LS.ldw16 + kt * 16 + 8 * hk);
+            }
+        if (KIND != CHAIN_LSTM) {
+#pragma unroll
+            for (int m = 0; m < UT * 4; ++m) wqf[m] = LS.wq[(long)((wave & 3) * 32 + r) * H + u0 + 2 * m + hk];
+        }
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            const int tp = 2 * sl + (tid >> 8);
+            float c = 0.f;
+            if (tp < NTILE && d.t0 > 0) {
+                const int b = row0 + (tp / UT) * 32 + ((tid & 255) >> 3), u = u0 + (tp % UT) * 8 + (tid & 7);
+                if (b < B) c = LS.c_out[((long)(d.t0 - 1) * B + b) * H + u];
+            }
+            cst[sl] = c;
+        }
+    }
+    // ---------------------------------------------------------------- A setup: item constants + state -> LDS (once)
+    int alen = 0;
+    if (hasA) {
+        for (int a = tid; a < A; a += NTH) vL[a] = AS.v[a];
+        for (int j = tid; j < Tp + 4; j += NTH) {
+            float ap = 0.f, cm = 0.f;
+            if (j < Tin) {
+                if (d.t0 > 0) {
+                    ap = AS.align[((long)ab_ * d.T + (d.t0 - 1)) * Tin + j];
+                    if (KIND == CHAIN_LSA) cm = AS.wcum[((long)ab_ * d.T + (d.t0 - 1)) * Tin + j];
+                } else if (KIND == CHAIN_SMA && j == 0) ap = 1.f;                     // attention.py:324-328
+            }
+            apL[j] = ap; cumL[j] = cm;
+        }
+        for (int i = tid; i < Jp * (A / 4); i += NTH) {
+            const int j = i / (A / 4), a4 = (i % (A / 4)) * 4;
+            *reinterpret_cast<f32x4*>(pmL + j * A + a4) = *reinterpret_cast<const f32x4*>(AS.pm + ((long)ab_ * Tin + j) * A + a4);
+        }
+        for (int i = tid; i < Jm * (EC / 4); i += NTH) {
+            const int j = i / (EC / 4), c4 = (i % (EC / 4)) * 4;
+            const f32x4 m4 = *reinterpret_cast<const f32x4*>(AS.memory + ((long)ab_ * Tin + j) * d.E + c0 + c4);
+            bf16x4 o; o[0] = (__bf16)m4[0]; o[1] = (__bf16)m4[1]; o[2] = (__bf16)m4[2]; o[3] = (__bf16)m4[3];
+            *reinterpret_cast<bf16x4*>(memL + j * EC + c4) = o;
+        }
+        alen = AS.lengths ? AS.lengths[ab_] : Tin;
+        if (d.max_pos > 0) alen = min(alen, d.max_pos);
+    }
+    __syncthreads();
+
+    const float dscale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
+    const RngKey kh = rng_key(d.seed, LS.site_h), kc = rng_key(d.seed, LS.site_c), kn = rng_key(d.seed, AS.site_noise);
+
+    for (int t = d.t0; t < d.t1; ++t) {
+        const unsigned ep = (unsigned)(t - d.t0);
+        const unsigned xin = (unsigned)(((t + 1) & 1) * d.NS) * G.xs_bytes;      // parity of step t-1
+        const unsigned xout = (unsigned)((t & 1) * d.NS) * G.xs_bytes;
+        // ======================================================================================= L(t)
+        if (hasL) {
+            // pre-activations of this step first: they do not depend on the exchange and arrive during the poll
+            float pre[NSLOT][4];
+#pragma unroll
+            for (int sl = 0; sl < NSLOT; ++sl) {
+                const int tp = 2 * sl + (tid >> 8);
+                const int b = min(row0 + (tp / UT) * 32 + ((tid & 255) >> 3), B - 1), u = u0 + (tp % UT) * 8 + (tid & 7);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pre[sl][g] = tp < NTILE ? LS.pre[((long)t * B + b) * 4 * H + g * H + u] : 0.f;
+            }
+            if (wave == 0 && !poll_counter(cntH_L, ep * (unsigned)G.NUG, d.err, 1u) && lane == 0) *abortw = 1;
+            __syncthreads();
+            if (*abortw) return;
+            const unsigned xl = xin + (unsigned)ls * G.xs_bytes + (unsigned)lane * 16u;
+            f32x16 acc[UT];
+            auto zero_acc = [&]() {
+#pragma unroll
+                for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[ut][e] = 0.f;
+            };
+            // K slice of wave w: k tiles [w*KH, (w+1)*KH) of the h part, [H/16 + w*KC, ...) of the ctx part
+            auto gemm_part = [&](int rt, int kt0, int i0, auto nk) {
+                constexpr int NK = decltype(nk)::value;
+                const int rtg = min(rg * RT + rt, G.MT - 1);
+                u32x4 af[NK > 0 ? NK : 1];
+#pragma unroll
+                for (int i = 0; i < NK; ++i)
+                    af[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xl + (unsigned)(((kt0 + i) * G.MT + rtg) * 1024), 0, SC1);
+#pragma unroll
+                for (int i = 0; i < NK; ++i)
+#pragma unroll
+                    for (int ut = 0; ut < UT; ++ut)
+                        acc[ut] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]), W[ut][i0 + i], acc[ut], 0, 0, 0);
+            };
+            // one row tile at a time keeps a single set of accumulators live; with one row tile per item the h part runs
+            // before the wait for the contexts (it only needs h_{t-1}, which the attention phase has long had)
+            if (RT == 1) { zero_acc(); gemm_part(0, wave * KH, 0, std::integral_constant<int, KH>{}); }
+            if (KC > 0) {
+                if (wave == 0 && !poll_counter(cntC_L, ep * nA_per_step, d.err, 2u) && lane == 0) *abortw = 1;
+                __syncthreads();
+                if (*abortw) return;
+            }
+            // ---- fixed-order sum of the 8 K-split partial tiles, gates, cell update, dropout (model.py:340-346, 371-373)
+            float sv[NSLOT][7];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                if (RT > 1) { zero_acc(); gemm_part(rt, wave * KH, 0, std::integral_constant<int, KH>{}); }
+                if (KC > 0) gemm_part(rt, H / 16 + wave * KC, KH, std::integral_constant<int, KC>{});
+#pragma unroll
+                for (int ut = 0; ut < UT; ++ut) {
+                    const int tp = rt * UT + ut;
+                    if (tp > 0) __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        partL[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk) * PPR + r] = acc[ut][e];
+                    __syncthreads();
+                    if ((tid >> 8) == (tp & 1)) {
+                        const int sl = tp >> 1;
+                        const int bl = (tid & 255) >> 3, uu = tid & 7;
+                        const int b = row0 + rt * 32 + bl, u = u0 + ut * 8 + uu;
+                        float g4[4];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float sum = 0.f;
+#pragma unroll
+                            for (int w = 0; w < NWV; ++w) sum += partL[(w * 32 + bl) * PPR + g * 8 + uu];
+                            g4[g] = sum + pre[sl][g];
+                        }
+                        const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]), og = sigmoidf_(g4[3]);
+                        const float cn = fg * cst[sl] + ig * gg;
+                        const float hn = og * tanhf(cn);
+                        float ho = hn, co = cn;
+                        if (d.drop_p > 0.f) {
+                            const uint32_t idx = (uint32_t)(((long)t * B + b) * H + u);
+                            ho = rng_keep(kh, idx, d.drop_p) ? hn * dscale : 0.f;
+                            co = rng_keep(kc, idx, d.drop_p) ? cn * dscale : 0.f;
+                        }
+                        if (b >= B) { ho = 0.f; co = 0.f; }
+                        cst[sl] = co;
+                        sv[sl][0] = ig; sv[sl][1] = fg; sv[sl][2] = gg; sv[sl][3] = og; sv[sl][4] = cn; sv[sl][5] = co; sv[sl][6] = ho;
+                        hsL[(rt * 32 + bl) * HSP + ut * 8 + uu] = ho;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- h_t in fragment order (bf16) for the next step's GEMMs
+            if (wave < RT && rg * RT + wave < G.MT) {
+                const int rtg = rg * RT + wave;
+                if (UT == 2 || hk == 0) {
+                    const int kh8 = UT == 2 ? hk : ((u0 >> 3) & 1);           // which half of the 16-wide k tile
+                    const float* hp = hsL + (wave * 32 + r) * HSP + (UT == 2 ? hk * 8 : 0);
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(hp), hi = *reinterpret_cast<const f32x4*>(hp + 4);
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { o[j] = (__bf16)lo[j]; o[4 + j] = (__bf16)hi[j]; }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsX,
+                        xout + (unsigned)ls * G.xs_bytes + (unsigned)((((u0 >> 4) * G.MT + rtg) * 64 + kh8 * 32 + r) * 16), 0, SC1);
+                }
+            }
+            if (KIND != CHAIN_LSTM) {
+                // ---- fp32 partial of the query projection over this unit group (attention.py:68,368): exact fma chains
+                if (wave < 4 * RT) {
+                    const int ct = wave & 3, rt = wave >> 2;
+                    f32x16 qa;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) qa[e] = 0.f;
+#pragma unroll
+                    for (int m = 0; m < UT * 4; ++m)
+                        qa = __builtin_amdgcn_mfma_f32_32x32x2f32(hsL[(rt * 32 + r) * HSP + 2 * m + hk], wqf[m], qa, 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) qsL[(rt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk) * (A + 4) + ct * 32 + r] = qa[e];
+                }
+                __syncthreads();
+                const unsigned qb = (unsigned)(((ls * G.NRG + rg) * G.NUG + ug) * (32 * RT)) * (unsigned)(A * 4);
+                for (int i = tid; i < RT * 32 * (A / 4); i += NTH) {
+                    const int row = i / (A / 4), a4 = (i % (A / 4)) * 4;
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(qsL + row * (A + 4) + a4);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), rsQ, qb + (unsigned)((row * A + a4) * 4), 0, SC1);
+                }
+            }
+            publish(cntH_L);
+            // ---- saved activations (backward pass) and the module-level outputs: plain stores, off the critical path
+#pragma unroll
+            for (int sl = 0; sl < NSLOT; ++sl) {
+                const int tp = 2 * sl + (tid >> 8);
+                const int b = row0 + (tp / UT) * 32 + ((tid & 255) >> 3), u = u0 + (tp % UT) * 8 + (tid & 7);
+                if (tp < NTILE && b < B) {
+                    const long rb = (long)t * B + b;
+                    float* gp = LS.gates + rb * 4 * H + u;
+                    gp[0] = sv[sl][0]; gp[H] = sv[sl][1]; gp[2 * H] = sv[sl][2]; gp[3 * H] = sv[sl][3];
+                    LS.c_new[rb * H + u] = sv[sl][4];
+                    LS.c_out[rb * H + u] = sv[sl][5];
+                    LS.h_out[rb * LS.ldh + u] = sv[sl][6];
+                    LS.h16_out[rb * LS.ldh16 + u] = (__bf16)sv[sl][6];
+                }
+            }
+        }
+        // ======================================================================================= A(t)
+        if (hasA) {
+            if (wave == 0 && !poll_counter(cntH_A, (ep + 1) * (unsigned)G.NUG, d.err, 3u) && lane == 0) *abortw = 1;
+            __syncthreads();
+            if (*abortw) return;
+            // ---- query = ordered sum of the unit groups' partials
+            {
+                const int pg = tid >> 5, a4 = (tid & 31) * 4;
+                const unsigned qb = (unsigned)((as * G.NRG + arg) * G.NUG) * (unsigned)(32 * RT * A * 4) + (unsigned)((arow * A + a4) * 4);
+                f32x4 accq = {0.f, 0.f, 0.f, 0.f};
+                constexpr int QU = 4;
+                for (int i0 = pg; i0 < G.NUG; i0 += 16 * QU) {
+                    u32x4 pv[QU];
+#pragma unroll
+                    for (int k = 0; k < QU; ++k)
+                        pv[k] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, qb + (unsigned)min(i0 + 16 * k, G.NUG - 1) * (unsigned)(32 * RT * A * 4), 0, SC1);
+#pragma unroll
+                    for (int k = 0; k < QU; ++k) if (i0 + 16 * k < G.NUG) accq += __builtin_bit_cast(f32x4, pv[k]);
+                }
+                *reinterpret_cast<f32x4*>(redL + pg * A + a4) = accq;
+            }
+            __syncthreads();
+            if (tid < A) {
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) sum += redL[k * A + tid];
+                qL[tid] = sum;
+                if (part == 0) AS.qs[((long)t * B + ab_) * A + tid] = sum;
+            }
+            __syncthreads();
+            // ---- energies e_j = v . tanh(q + pm_j): 16 lanes per position, 8 channels per lane
+            {
+                const int gid = tid >> 4, sub = tid & 15;
+                for (int j = gid; j < Tp; j += NTH / 16) {
+                    float sum = 0.f;
+                    if (j < Tin) {
+                        const float* pr = j < Jp ? pmL + j * A : AS.pm + ((long)ab_ * Tin + j) * A;
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const int a = sub * 4 + 64 * k;
+                            const f32x4 pv = *reinterpret_cast<const f32x4*>(pr + a);
+                            const f32x4 qv = *reinterpret_cast<const f32x4*>(qL + a), vv = *reinterpret_cast<const f32x4*>(vL + a);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) sum += vv[c] * fast_tanh(qv[c] + pv[c]);
+                        }
+                    }
+                    sum += __shfl_xor(sum, 8, 64); sum += __shfl_xor(sum, 4, 64);
+                    sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 1, 64);
+                    if (sub == 0) eL[j] = sum;
+                }
+            }
+            __syncthreads();
+            if (KIND == CHAIN_SMA) {
+                // p = sigmoid(e + noise) ; a_t[j] = a_{t-1}[j] p_j + a_{t-1}[j-1] (1 - p_{j-1})      (attention.py:337-348)
+                for (int j = tid; j < Tin; j += NTH) {
+                    float ev = eL[j];
+                    if (j >= alen) ev = d.mask_value;
+                    if (d.noise_std > 0.f) ev += d.noise_std * rng_normal(kn, (uint32_t)(((long)t * B + ab_) * Tin + j));
+                    const float p = fast_sigmoid(ev);
+                    eL[j] = p;
+                    if (part == 0) AS.psel[((long)ab_ * d.T + t) * Tin + j] = p;
+                }
+                __syncthreads();
+                for (int j = tid; j < Tin; j += NTH) {
+                    float a = apL[j] * eL[j];
+                    if (j > 0) a += apL[j - 1] * (1.0f - eL[j - 1]);
+                    anL[j] = a;
+                    if (part == 0) AS.align[((long)ab_ * d.T + t) * Tin + j] = a;
+                }
+            }
+            __syncthreads();
+            // ---- context columns [c0, c0 + EC): wave w sums positions j = w, w + 8, ...; lanes stride the columns 4 at a time
+            {
+                const int ncl = EC / 4;                                  // lanes in use per wave pass
+                for (int cb = 0; cb < ncl; cb += 64) {
+                    const int cl = cb + lane;
+                    f32x4 accc = {0.f, 0.f, 0.f, 0.f};
+                    if (cl < ncl) {
+                        for (int j = wave; j < Tin; j += NWV) {
+                            const float aw = anL[j];
+                            f32x4 mv;
+                            if (j < Jm) {
+                                const bf16x4 mb = *reinterpret_cast<const bf16x4*>(memL + j * EC + cl * 4);
+                                mv = f32x4{(float)mb[0], (float)mb[1], (float)mb[2], (float)mb[3]};
+                            } else {
+                                mv = *reinterpret_cast<const f32x4*>(AS.memory + ((long)ab_ * Tin + j) * d.E + c0 + cl * 4);
+                            }
+                            accc += aw * mv;
+                        }
+                        *reinterpret_cast<f32x4*>(credL + wave * EC + cl * 4) = accc;
+                    }
+                }
+            }
+            __syncthreads();
+            for (int c = tid; c < EC; c += NTH) {
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWV; ++w) sum += credL[w * EC + c];
+                csL[c] = sum;
+            }
+            for (int j = tid; j < Tin; j += NTH) apL[j] = anL[j];          // recurrent state for the next step
+            __syncthreads();
+            // ---- ctx_t in fragment order (bf16): 8 columns per lane
+            if (tid < EC / 8) {
+                const int pc = c0 / 8 + tid;                                 // 8-column piece of the context row
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(csL + tid * 8), hi = *reinterpret_cast<const f32x4*>(csL + tid * 8 + 4);
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { o[j] = (__bf16)lo[j]; o[4 + j] = (__bf16)hi[j]; }
+                const int kt = H / 16 + pc / 2;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsX,
+                    xout + (unsigned)as * G.xs_bytes + (unsigned)(((kt * G.MT + ab_ / 32) * 64 + (pc & 1) * 32 + (ab_ & 31)) * 16), 0, SC1);
+            }
+            publish(cntC_A);
+            {
+                const long rb = (long)t * B + ab_;
+                for (int c = tid; c < EC; c += NTH) {
+                    const float x = csL[c];
+                    d.din[rb * d.WD + AS.coff + c0 + c] = x;
+                    d.dout[rb * d.WO + AS.ctx2off + c0 + c] = x;
+                    d.din16[rb * d.WD + AS.coff + c0 + c] = (__bf16)x;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+static int g_chain_cus[16] = {0};
+
+int chain_device_cus() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    int& c = g_chain_cus[dev & 15];
+    if (c == 0) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+        c = p.multiProcessorCount;
+    }
+    return c;
+}
+
+// Picks the tiling for a shape; returns false when the persistent kernel does not cover it.
+bool chain_plan(ChainDesc& d) {
+    if (d.H != 1024 || d.B < 1 || d.B > 128) return false;
+    if (d.kind != CHAIN_LSTM && (d.E != 512 || d.A != 128 || d.NS < 1 || d.NS > 2)) return false;
+    if (d.kind == CHAIN_LSA) return false;                        // (location-sensitive variant: not yet in this kernel)
+    const int MT = (d.B + 31) / 32;
+    if (d.kind == CHAIN_LSTM) { d.UT = 1; d.RT = MT <= 2 ? MT : 2; d.CS = 1; d.NS = 1; }
+    else {
+        d.RT = MT <= 2 ? 1 : 2;
+        d.UT = (d.NS * (d.H / 8) * ((MT + d.RT - 1) / d.RT) <= 256) ? 1 : 2;
+        d.CS = d.NS * d.B * 4 <= 256 ? 4 : d.NS * d.B * 2 <= 256 ? 2 : 1;
+    }
+    const Geo g = geo_of(d, d.UT, d.RT);
+    if (g.nL > 256 || g.nA > 256) return false;
+    if (chain_device_cus() < 256) return false;
+    // LDS residency: processed-memory rows first, then (bf16) memory rows, in what the largest stream leaves free
+    const int budget = (160 * 1024 - 256) / 4;
+    int tmax = 4;
+    for (int s = 0; s < d.NS && d.kind != CHAIN_LSTM; ++s) tmax = std::max(tmax, d.st[s].Tin);
+    d.lds_Tin = tmax; d.lds_Jp = 0; d.lds_Jm = 0;
+    const int fixed = lds_of(d, d.UT, d.RT, tmax, 0, 0).total;
+    if (fixed > budget) return false;
+    if (d.kind != CHAIN_LSTM) {
+        const int EC = d.E / d.CS;
+        int left = budget - fixed;
+        d.lds_Jp = std::min(tmax, left / d.A); left -= d.lds_Jp * d.A;
+        d.lds_Jm = std::min(tmax, left / (EC / 2)) & ~1;
+        for (int s = 0; s < d.NS; ++s) { d.Jp[s] = std::min(d.st[s].Tin, d.lds_Jp); d.Jm[s] = std::min(d.st[s].Tin, d.lds_Jm); }
+        if (getenv("T2_CHAIN_NO_RESIDENT")) { d.Jp[0] = d.Jp[1] = d.Jm[0] = d.Jm[1] = 0; }
+    }
+    return true;
+}
+
+size_t chain_exchange_bytes(const ChainDesc& d, size_t* x_bytes, size_t* q_bytes) {
+    const Geo g = geo_of(d, d.UT, d.RT);
+    *x_bytes = (size_t)2 * d.NS * g.xs_bytes;
+    *q_bytes = d.kind == CHAIN_LSTM ? 16 : (size_t)d.NS * g.NRG * g.NUG * 32 * d.RT * d.A * 4;
+    return *x_bytes + *q_bytes;
+}
+
+template <int UT, int RT, int KC, int KIND>
+static int chain_launch(const ChainDesc& d, hipStream_t s) {
+    const Lds m = lds_of(d, UT, RT, d.lds_Tin, d.lds_Jp, d.lds_Jm);
+    const size_t smem = (size_t)m.total * sizeof(float);
+    auto kernel = chain_fwd_kernel<UT, RT, 8, KC, KIND>;
+    T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const Geo g = geo_of(d, UT, RT);
+    const int grid = std::max(g.nL, g.nA);
+    T2_CHECK_HIP(hipMemsetAsync(d.cnt, 0, (size_t)d.NS * g.NRG * 2 * CNT_STRIDE * sizeof(unsigned), s));
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(NTH), smem, s, d);
+    T2_LAUNCH_CHECK();
+    return 0;
+}
+
+int chain_fwd(const ChainDesc& d, hipStream_t s) {
+    T2_REQUIRE(d.t1 > d.t0 && d.t0 >= 0, "chain_fwd: bad step range [%d,%d)", d.t0, d.t1);
+    T2_REQUIRE(d.X && d.cnt && d.err && (d.kind == CHAIN_LSTM || d.Q), "chain_fwd: exchange buffers missing");
+    if (d.kind == CHAIN_LSTM) {
+        if (d.RT == 1) return chain_launch<1, 1, 0, CHAIN_LSTM>(d, s);
+        return chain_launch<1, 2, 0, CHAIN_LSTM>(d, s);
+    }
+    T2_REQUIRE(d.kind == CHAIN_SMA, "chain_fwd: attention kind %d not covered", d.kind);
+    if (d.UT == 1 && d.RT == 1) return chain_launch<1, 1, 4, CHAIN_SMA>(d, s);
+    if (d.UT == 2 && d.RT == 1) return chain_launch<2, 1, 4, CHAIN_SMA>(d, s);
+    if (d.UT == 2 && d.RT == 2) return chain_launch<2, 2, 4, CHAIN_SMA>(d, s);
+    T2_REQUIRE(false, "chain_fwd: tiling UT=%d RT=%d not instantiated", d.UT, d.RT);
+    return -1;
+}
+
+}  // namespace t2

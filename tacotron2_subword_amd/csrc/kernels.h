@@ -184,6 +184,39 @@ __host__ __device__ inline size_t dca_acc_floats(int A) { return (size_t)2 * A +
 struct AttnBwdDesc { AttnBwdStream st[2]; int nstreams; int B, A, E; int first; int kind, F, Kc; int nsplit; };   // nsplit: SMA only
 int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s);
 
+
+// ------------------------------------------------------------------ persistent decoder chains (chain.hip)
+// Many consecutive steps of a teacher-forced recurrence in one launch, recurrent weights resident in registers.
+enum ChainKind : int { CHAIN_LSTM = 0, CHAIN_SMA = 1, CHAIN_LSA = 2 };
+struct ChainStream {
+    const __bf16* w16; long ldw16;        // [4H][K] K-contiguous bf16 shadow: [W_hh | W_ih[:, P:]] (K = H + E) or W_hh (K = H)
+    const float* pre;                     // [T][B][4H] hoisted input-side pre-activations (+ biases)
+    const float* wq;                      // [A][H] query projection (attention kinds)
+    float* gates; float* c_new; float* c_out;   // saved activations [T][B][4H], [T][B][H], [T][B][H]
+    float* h_out; long ldh;               // h(t) fp32: h_out[(t*B + b)*ldh + u]
+    __bf16* h16_out; long ldh16;          // bf16 copy, same indexing
+    int coff, ctx2off;                    // column of this stream's context in a DIN / DOUT row
+    const float* pm; const float* memory; const int* lengths; int Tin;   // [B,Tin,A], [B,Tin,E], [B] (nullable)
+    float* align; float* psel; float* wcum; float* qs;                   // [B,T,Tin] x3, [T,B,A]
+    const float* v; const float* loc_conv; const float* loc_dense;
+    uint32_t site_h, site_c, site_noise;
+};
+struct ChainDesc {
+    ChainStream st[2]; int NS, B, T, t0, t1;
+    int H, E, A, WD, WO;
+    float* din; __bf16* din16; float* dout;        // [T][B][WD] (fp32 + bf16 shadow), [T][B][WO]
+    int kind, F, Kc, max_pos; float mask_value;
+    float drop_p, noise_std; uint64_t seed;
+    unsigned char* X; float* Q; unsigned* cnt; unsigned* err; unsigned q_bytes;   // exchange buffers (chain_exchange_bytes)
+    int UT, RT, CS;                                // tiling chosen by chain_plan
+    int lds_Tin, lds_Jp, lds_Jm; int Jp[2], Jm[2]; // LDS residency: processed-memory / memory rows kept on chip
+};
+bool chain_plan(ChainDesc& d);                     // fills UT/RT/CS and the residency fields; false = shape not covered
+size_t chain_exchange_bytes(const ChainDesc& d, size_t* x_bytes, size_t* q_bytes);
+constexpr size_t kChainCntBytes = 2 * 4 * 2 * 128; // arrival counters: [NS][row groups <= 4][2] lines of 128 B
+int chain_fwd(const ChainDesc& d, hipStream_t s);
+int chain_device_cus();
+
 // ------------------------------------------------------------------ decode-step tail (infer.hip)
 // projection + stop rule of step t and both prenets of step t+1, one workgroup per batch item
 struct StepTailDesc {
