@@ -33,6 +33,27 @@
 
 #include "kernels.h"
 
+// Diagnostic build (T2_EXTRA_HIPCC_FLAGS=-DT2_STAMPS, scripts/chain_stamps.py): thread 0 of every workgroup adds the
+// realtime-counter ticks (100 MHz) of each segment of a step into t2_chain_stamps[workgroup][segment].
+#ifdef T2_STAMPS
+__device__ unsigned long long t2_chain_stamps[256 * 16];
+extern "C" int t2_debug_read_chain_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(t2_chain_stamps), sizeof(unsigned long long) * n);
+}
+extern "C" int t2_debug_clear_chain_stamps(void) {
+    static unsigned long long z[256 * 16];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(t2_chain_stamps), z, sizeof(z));
+}
+#define T2_CSTAMP(i)                                                                              \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); stamp_acc[i] += n_ - stamp_last; stamp_last = n_; } \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+#else
+#define T2_CSTAMP(i)
+#endif
+
 namespace t2 {
 
 namespace {
@@ -208,24 +229,44 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
     const float dscale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
     const RngKey kh = rng_key(d.seed, LS.site_h), kc = rng_key(d.seed, LS.site_c), kn = rng_key(d.seed, AS.site_noise);
 
+    float pre_next[NSLOT][4];
+    auto load_pre = [&](int t, int tid) {
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            const int tp = 2 * sl + (tid >> 8);
+            const int b = min(row0 + (tp / UT) * 32 + ((tid & 255) >> 3), B - 1), u = u0 + (tp % UT) * 8 + (tid & 7);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre_next[sl][g] = (hasL && tp < NTILE) ? LS.pre[((long)t * B + b) * 4 * H + g * H + u] : 0.f;
+        }
+    };
+    load_pre(d.t0, tid);
+#ifdef T2_STAMPS
+    unsigned long long stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int t = d.t0; t < d.t1; ++t) {
         const unsigned ep = (unsigned)(t - d.t0);
+        // An opaque copy of the thread index per step: every address that is rebuilt from it inside the step stays inside
+        // the step.  Left to itself hipcc hoists dozens of per-thread 64-bit addresses out of the time loop and keeps them
+        // live next to the 96 weight registers (spills).
+        int tv = threadIdx.x;
+        asm volatile("" : "+v"(tv));
         const unsigned xin = (unsigned)(((t + 1) & 1) * d.NS) * G.xs_bytes;      // parity of step t-1
         const unsigned xout = (unsigned)((t & 1) * d.NS) * G.xs_bytes;
         // ======================================================================================= L(t)
         if (hasL) {
-            // pre-activations of this step first: they do not depend on the exchange and arrive during the poll
+            // pre-activations of this step were requested one step ago (vector-memory operations complete in order: a cold
+            // HBM read issued here would hold back every exchange load of the step behind it)
             float pre[NSLOT][4];
 #pragma unroll
-            for (int sl = 0; sl < NSLOT; ++sl) {
-                const int tp = 2 * sl + (tid >> 8);
-                const int b = min(row0 + (tp / UT) * 32 + ((tid & 255) >> 3), B - 1), u = u0 + (tp % UT) * 8 + (tid & 7);
+            for (int sl = 0; sl < NSLOT; ++sl)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) pre[sl][g] = tp < NTILE ? LS.pre[((long)t * B + b) * 4 * H + g * H + u] : 0.f;
-            }
+                for (int g = 0; g < 4; ++g) pre[sl][g] = pre_next[sl][g];
+            T2_CSTAMP(15);
             if (wave == 0 && !poll_counter(cntH_L, ep * (unsigned)G.NUG, d.err, 1u) && lane == 0) *abortw = 1;
             __syncthreads();
             if (*abortw) return;
+            T2_CSTAMP(0);
             const unsigned xl = xin + (unsigned)ls * G.xs_bytes + (unsigned)lane * 16u;
             f32x16 acc[UT];
             auto zero_acc = [&]() {
@@ -251,17 +292,20 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             // one row tile at a time keeps a single set of accumulators live; with one row tile per item the h part runs
             // before the wait for the contexts (it only needs h_{t-1}, which the attention phase has long had)
             if (RT == 1) { zero_acc(); gemm_part(0, wave * KH, 0, std::integral_constant<int, KH>{}); }
+            T2_CSTAMP(1);
             if (KC > 0) {
                 if (wave == 0 && !poll_counter(cntC_L, ep * nA_per_step, d.err, 2u) && lane == 0) *abortw = 1;
                 __syncthreads();
                 if (*abortw) return;
             }
+            T2_CSTAMP(2);
             // ---- fixed-order sum of the 8 K-split partial tiles, gates, cell update, dropout (model.py:340-346, 371-373)
             float sv[NSLOT][7];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 if (RT > 1) { zero_acc(); gemm_part(rt, wave * KH, 0, std::integral_constant<int, KH>{}); }
                 if (KC > 0) gemm_part(rt, H / 16 + wave * KC, KH, std::integral_constant<int, KC>{});
+                T2_CSTAMP(14);
 #pragma unroll
                 for (int ut = 0; ut < UT; ++ut) {
                     const int tp = rt * UT + ut;
@@ -282,9 +326,9 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                             for (int w = 0; w < NWV; ++w) sum += partL[(w * 32 + bl) * PPR + g * 8 + uu];
                             g4[g] = sum + pre[sl][g];
                         }
-                        const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]), og = sigmoidf_(g4[3]);
+                        const float ig = fast_sigmoid(g4[0]), fg = fast_sigmoid(g4[1]), gg = fast_tanh(g4[2]), og = fast_sigmoid(g4[3]);
                         const float cn = fg * cst[sl] + ig * gg;
-                        const float hn = og * tanhf(cn);
+                        const float hn = og * fast_tanh(cn);
                         float ho = hn, co = cn;
                         if (d.drop_p > 0.f) {
                             const uint32_t idx = (uint32_t)(((long)t * B + b) * H + u);
@@ -299,6 +343,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 }
             }
             __syncthreads();
+            T2_CSTAMP(3);
             // ---- h_t in fragment order (bf16) for the next step's GEMMs
             if (wave < RT && rg * RT + wave < G.MT) {
                 const int rtg = rg * RT + wave;
@@ -328,18 +373,21 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 }
                 __syncthreads();
                 const unsigned qb = (unsigned)(((ls * G.NRG + rg) * G.NUG + ug) * (32 * RT)) * (unsigned)(A * 4);
-                for (int i = tid; i < RT * 32 * (A / 4); i += NTH) {
+                for (int i = tv; i < RT * 32 * (A / 4); i += NTH) {
                     const int row = i / (A / 4), a4 = (i % (A / 4)) * 4;
                     const f32x4 v4 = *reinterpret_cast<const f32x4*>(qsL + row * (A + 4) + a4);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), rsQ, qb + (unsigned)((row * A + a4) * 4), 0, SC1);
                 }
             }
+            T2_CSTAMP(4);
             publish(cntH_L);
+            T2_CSTAMP(5);
             // ---- saved activations (backward pass) and the module-level outputs: plain stores, off the critical path
+#ifndef T2_CHAIN_NOSAVE
 #pragma unroll
             for (int sl = 0; sl < NSLOT; ++sl) {
-                const int tp = 2 * sl + (tid >> 8);
-                const int b = row0 + (tp / UT) * 32 + ((tid & 255) >> 3), u = u0 + (tp % UT) * 8 + (tid & 7);
+                const int tp = 2 * sl + (tv >> 8);
+                const int b = row0 + (tp / UT) * 32 + ((tv & 255) >> 3), u = u0 + (tp % UT) * 8 + (tv & 7);
                 if (tp < NTILE && b < B) {
                     const long rb = (long)t * B + b;
                     float* gp = LS.gates + rb * 4 * H + u;
@@ -350,12 +398,17 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                     LS.h16_out[rb * LS.ldh16 + u] = (__bf16)sv[sl][6];
                 }
             }
+#endif
+            if (!hasA && t + 1 < d.t1) load_pre(t + 1, tv);
         }
         // ======================================================================================= A(t)
         if (hasA) {
+            const int tid = tv, lane = tid & 63, wave = tid >> 6;
+            T2_CSTAMP(6);
             if (wave == 0 && !poll_counter(cntH_A, (ep + 1) * (unsigned)G.NUG, d.err, 3u) && lane == 0) *abortw = 1;
             __syncthreads();
             if (*abortw) return;
+            T2_CSTAMP(7);
             // ---- query = ordered sum of the unit groups' partials
             {
                 const int pg = tid >> 5, a4 = (tid & 31) * 4;
@@ -371,6 +424,9 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                     for (int k = 0; k < QU; ++k) if (i0 + 16 * k < G.NUG) accq += __builtin_bit_cast(f32x4, pv[k]);
                 }
                 *reinterpret_cast<f32x4*>(redL + pg * A + a4) = accq;
+                // the next step's pre-activations (cold HBM rows): requested here, where this wave needs nothing from
+                // memory until the context is published (vector-memory operations complete in order)
+                if (t + 1 < d.t1) load_pre(t + 1, tv);
             }
             __syncthreads();
             if (tid < A) {
@@ -381,33 +437,67 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 if (part == 0) AS.qs[((long)t * B + ab_) * A + tid] = sum;
             }
             __syncthreads();
-            // ---- energies e_j = v . tanh(q + pm_j): 16 lanes per position, 8 channels per lane
+            T2_CSTAMP(8);
+            // ---- energies e_j = v . tanh(q + pm_j) = sum(v) - 2 sum_a v_a / (exp(2 (q_a + pm_ja)) + 1): 16 lanes per position,
+            // 8 channels per lane, two positions in flight per lane group
             {
                 const int gid = tid >> 4, sub = tid & 15;
-                for (int j = gid; j < Tp; j += NTH / 16) {
+                f32x4 qv[2], vv[2];
+                float vsum = 0.f;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    qv[k] = *reinterpret_cast<const f32x4*>(qL + sub * 4 + 64 * k);
+                    vv[k] = *reinterpret_cast<const f32x4*>(vL + sub * 4 + 64 * k);
+                    qv[k] *= 2.0f * 1.44269504088896341f;                  // exp(2u) = exp2(2 log2(e) u)
+                    vsum += (vv[k][0] + vv[k][1]) + (vv[k][2] + vv[k][3]);
+                }
+                constexpr float K2 = 2.0f * 1.44269504088896341f;
+                // LDS-resident rows and L2 rows go through separate loops: one loop with a choice per row makes hipcc
+                // select between the two pointers and read both through flat_load
+                auto dot = [&](const f32x4 (&pv)[2]) {
                     float sum = 0.f;
-                    if (j < Tin) {
-                        const float* pr = j < Jp ? pmL + j * A : AS.pm + ((long)ab_ * Tin + j) * A;
 #pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            const int a = sub * 4 + 64 * k;
-                            const f32x4 pv = *reinterpret_cast<const f32x4*>(pr + a);
-                            const f32x4 qv = *reinterpret_cast<const f32x4*>(qL + a), vv = *reinterpret_cast<const f32x4*>(vL + a);
+                    for (int k = 0; k < 2; ++k)
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) sum += vv[c] * fast_tanh(qv[c] + pv[c]);
-                        }
+                        for (int c = 0; c < 4; ++c)
+                            sum += vv[k][c] * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(fmaf(pv[k][c], K2, qv[k][c])) + 1.0f);
+                    return vsum - 2.0f * sum;
+                };
+                auto finish = [&](int j, float s0) {
+                    s0 += __shfl_xor(s0, 8, 64); s0 += __shfl_xor(s0, 4, 64);
+                    s0 += __shfl_xor(s0, 2, 64); s0 += __shfl_xor(s0, 1, 64);
+                    if (sub == 0) eL[j] = s0;
+                };
+                const int nres = min(Jp, Tin);
+                int j = gid;
+                for (; j < nres; j += 2 * (NTH / 16)) {                  // resident rows, two positions in flight
+                    const int j1 = j + NTH / 16;
+                    f32x4 p0[2], p1[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        p0[k] = *reinterpret_cast<const f32x4*>(pmL + j * A + sub * 4 + 64 * k);
+                        p1[k] = *reinterpret_cast<const f32x4*>(pmL + min(j1, nres - 1) * A + sub * 4 + 64 * k);
                     }
-                    sum += __shfl_xor(sum, 8, 64); sum += __shfl_xor(sum, 4, 64);
-                    sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 1, 64);
-                    if (sub == 0) eL[j] = sum;
+                    finish(j, dot(p0));
+                    if (j1 < nres) finish(j1, dot(p1));
+                }
+                for (j = nres + gid; j < Tin; j += NTH / 16) {           // rows beyond the LDS budget: from L2
+                    const float* pr = AS.pm + ((long)ab_ * Tin + j) * A + sub * 4;
+                    f32x4 p0[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) p0[k] = *reinterpret_cast<const f32x4*>(pr + 64 * k);
+                    finish(j, dot(p0));
                 }
             }
             __syncthreads();
+            T2_CSTAMP(9);
             if (KIND == CHAIN_SMA) {
                 // p = sigmoid(e + noise) ; a_t[j] = a_{t-1}[j] p_j + a_{t-1}[j-1] (1 - p_{j-1})      (attention.py:337-348)
+                float maskv = d.mask_value;
+                asm volatile("" : "+v"(maskv));             // opaque: otherwise hipcc selects between &eL[j] and &d.mask_value and reads through flat_load
                 for (int j = tid; j < Tin; j += NTH) {
                     float ev = eL[j];
-                    if (j >= alen) ev = d.mask_value;
+                    if (j >= alen) ev = maskv;
                     if (d.noise_std > 0.f) ev += d.noise_std * rng_normal(kn, (uint32_t)(((long)t * B + ab_) * Tin + j));
                     const float p = fast_sigmoid(ev);
                     eL[j] = p;
@@ -422,24 +512,23 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 }
             }
             __syncthreads();
-            // ---- context columns [c0, c0 + EC): wave w sums positions j = w, w + 8, ...; lanes stride the columns 4 at a time
+            T2_CSTAMP(10);
+            // ---- context columns [c0, c0 + EC): wave w sums positions j = w, w + 8, ...; lanes stride the columns 4 at a time;
+            // resident rows (bf16 in LDS) and L2 rows (fp32) in separate loops
             {
-                const int ncl = EC / 4;                                  // lanes in use per wave pass
+                const int ncl = EC / 4, nres = min(Jm, Tin);
                 for (int cb = 0; cb < ncl; cb += 64) {
                     const int cl = cb + lane;
-                    f32x4 accc = {0.f, 0.f, 0.f, 0.f};
                     if (cl < ncl) {
-                        for (int j = wave; j < Tin; j += NWV) {
-                            const float aw = anL[j];
-                            f32x4 mv;
-                            if (j < Jm) {
-                                const bf16x4 mb = *reinterpret_cast<const bf16x4*>(memL + j * EC + cl * 4);
-                                mv = f32x4{(float)mb[0], (float)mb[1], (float)mb[2], (float)mb[3]};
-                            } else {
-                                mv = *reinterpret_cast<const f32x4*>(AS.memory + ((long)ab_ * Tin + j) * d.E + c0 + cl * 4);
-                            }
-                            accc += aw * mv;
+                        f32x4 accc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+                        for (int j = wave; j < nres; j += NWV) {
+                            const bf16x4 mb = *reinterpret_cast<const bf16x4*>(memL + j * EC + cl * 4);
+                            accc += anL[j] * f32x4{(float)mb[0], (float)mb[1], (float)mb[2], (float)mb[3]};
                         }
+#pragma unroll 4
+                        for (int j = nres + wave; j < Tin; j += NWV)
+                            accc += anL[j] * *reinterpret_cast<const f32x4*>(AS.memory + ((long)ab_ * Tin + j) * d.E + c0 + cl * 4);
                         *reinterpret_cast<f32x4*>(credL + wave * EC + cl * 4) = accc;
                     }
                 }
@@ -464,7 +553,10 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsX,
                     xout + (unsigned)as * G.xs_bytes + (unsigned)(((kt * G.MT + ab_ / 32) * 64 + (pc & 1) * 32 + (ab_ & 31)) * 16), 0, SC1);
             }
+            T2_CSTAMP(11);
             publish(cntC_A);
+            T2_CSTAMP(12);
+#ifndef T2_CHAIN_NOSAVE
             {
                 const long rb = (long)t * B + ab_;
                 for (int c = tid; c < EC; c += NTH) {
@@ -474,8 +566,14 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                     d.din16[rb * d.WD + AS.coff + c0 + c] = (__bf16)x;
                 }
             }
+#endif
+            T2_CSTAMP(13);
         }
     }
+#ifdef T2_STAMPS
+    if (tid == 0 && (KIND != CHAIN_LSTM) == (T2_STAMPS != 2))     // -DT2_STAMPS=1: the attention chain, =2: the decoder-LSTM chain
+        for (int i = 0; i < 16; ++i) t2_chain_stamps[wg * 16 + i] += stamp_acc[i];
+#endif
 }
 
 }  // namespace
