@@ -86,6 +86,22 @@ __device__ __forceinline__ bool poll_counter(const unsigned* cnt, unsigned want,
         __builtin_amdgcn_s_sleep(2);
     }
 }
+// two counters in one request: lane 0 reads cnt0, every other lane cnt1
+__device__ __forceinline__ bool poll_counters2(const unsigned* cnt0, unsigned want0, const unsigned* cnt1, unsigned want1, unsigned* err, unsigned code) {
+    const bool first = (threadIdx.x & 63) == 0;
+    const unsigned* p = first ? cnt0 : cnt1;
+    const unsigned want = first ? want0 : want1;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        const unsigned v = __hip_atomic_load(p, T2_RLX_AGENT);
+        if (__all(v >= want)) return true;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_TICKS) {
+            if (first) atomicMax(err, code);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
 // after the payload stores of every wave: drain (every storing wave), workgroup barrier, one lane signals
 __device__ __forceinline__ void publish(unsigned* cnt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -240,71 +256,122 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
         }
     };
     load_pre(d.t0, tid);
+
+    // K slice of wave w: k tiles [w*KH, (w+1)*KH) of the h part, [H/16 + w*KC, ...) of the ctx part.  `step` selects the
+    // exchange buffer holding h / ctx of step `step`.
+    f32x16 acc[UT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ut][e] = 0.f;
+    };
+    auto frag_offset = [&](int step, int rt, int kt) {
+        const int rtg = min(rg * RT + rt, G.MT - 1);
+        return (unsigned)((step & 1) * d.NS + ls) * G.xs_bytes + (unsigned)lane * 16u + (unsigned)((kt * G.MT + rtg) * 1024);
+    };
+    auto gemm_part = [&](int step, int rt, int kt0, int i0, auto nk) {
+        constexpr int NK = decltype(nk)::value;
+        u32x4 af[NK > 0 ? NK : 1];
+#pragma unroll
+        for (int i = 0; i < NK; ++i) af[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, frag_offset(step, rt, kt0 + i), 0, SC1);
+#pragma unroll
+        for (int i = 0; i < NK; ++i)
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut)
+                acc[ut] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]), W[ut][i0 + i], acc[ut], 0, 0, 0);
+    };
+    // With one row tile per item (EARLY) the h fragments are requested BEFORE the wait for the contexts (h_{t-1} has long
+    // been complete: the attention phase waited for it) and consumed after it, so their latency hides in that wait.
+    constexpr bool EARLY = RT == 1;
+    u32x4 hf[EARLY ? KH : 1];
+    auto issue_h = [&](int step) {
+#pragma unroll
+        for (int i = 0; i < (EARLY ? KH : 1); ++i) hf[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, frag_offset(step, 0, wave * KH + i), 0, SC1);
+    };
+    auto mfma_h = [&]() {
+        zero_acc();
+#pragma unroll
+        for (int i = 0; i < (EARLY ? KH : 1); ++i)
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut)
+                acc[ut] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, hf[i]), W[ut][i], acc[ut], 0, 0, 0);
+    };
+
+    float sv[NSLOT][7];
+    // saved activations (backward pass) and module-level outputs: plain stores, always issued right AFTER the loads the
+    // step needs next (vector-memory operations complete in order: a store in front of a load delays the load)
+    auto store_L_saved = [&](int t, int tid) {
+#ifndef T2_CHAIN_NOSAVE
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            const int tp = 2 * sl + (tid >> 8);
+            const int b = row0 + (tp / UT) * 32 + ((tid & 255) >> 3), u = u0 + (tp % UT) * 8 + (tid & 7);
+            if (tp < NTILE && b < B) {
+                const long rb = (long)t * B + b;
+                float* gp = LS.gates + rb * 4 * H + u;
+                gp[0] = sv[sl][0]; gp[H] = sv[sl][1]; gp[2 * H] = sv[sl][2]; gp[3 * H] = sv[sl][3];
+                LS.c_new[rb * H + u] = sv[sl][4];
+                LS.c_out[rb * H + u] = sv[sl][5];
+                LS.h_out[rb * LS.ldh + u] = sv[sl][6];
+                LS.h16_out[rb * LS.ldh16 + u] = (__bf16)sv[sl][6];
+            }
+        }
+#endif
+    };
+    auto store_A_saved = [&](int t, int tid) {                        // context of step t (still in csL)
+#ifndef T2_CHAIN_NOSAVE
+        const long rb = (long)t * B + ab_;
+        for (int c = tid; c < EC; c += NTH) {
+            const float x = csL[c];
+            d.din[rb * d.WD + AS.coff + c0 + c] = x;
+            d.dout[rb * d.WO + AS.ctx2off + c0 + c] = x;
+            d.din16[rb * d.WD + AS.coff + c0 + c] = (__bf16)x;
+        }
+#endif
+    };
 #ifdef T2_STAMPS
     unsigned long long stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_last = __builtin_amdgcn_s_memrealtime();
 #endif
     for (int t = d.t0; t < d.t1; ++t) {
         const unsigned ep = (unsigned)(t - d.t0);
+        const bool more = t + 1 < d.t1;
         // An opaque copy of the thread index per step: every address that is rebuilt from it inside the step stays inside
         // the step.  Left to itself hipcc hoists dozens of per-thread 64-bit addresses out of the time loop and keeps them
         // live next to the 96 weight registers (spills).
         int tv = threadIdx.x;
         asm volatile("" : "+v"(tv));
-        const unsigned xin = (unsigned)(((t + 1) & 1) * d.NS) * G.xs_bytes;      // parity of step t-1
         const unsigned xout = (unsigned)((t & 1) * d.NS) * G.xs_bytes;
         // ======================================================================================= L(t)
         if (hasL) {
-            // pre-activations of this step were requested one step ago (vector-memory operations complete in order: a cold
-            // HBM read issued here would hold back every exchange load of the step behind it)
+            // pre-activations of this step were requested one step ago (a cold HBM read issued here would hold back every
+            // exchange load of the step behind it)
             float pre[NSLOT][4];
 #pragma unroll
             for (int sl = 0; sl < NSLOT; ++sl)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) pre[sl][g] = pre_next[sl][g];
             T2_CSTAMP(15);
-            if (wave == 0 && !poll_counter(cntH_L, ep * (unsigned)G.NUG, d.err, 1u) && lane == 0) *abortw = 1;
-            __syncthreads();
-            if (*abortw) return;
+            if (!EARLY || !hasA) {                  // (an attention item's workgroup has polled this counter in its A phase)
+                if (wave == 0 && !poll_counter(cntH_L, ep * (unsigned)G.NUG, d.err, 1u) && lane == 0) *abortw = 1;
+                __syncthreads();
+                if (*abortw) return;
+            }
             T2_CSTAMP(0);
-            const unsigned xl = xin + (unsigned)ls * G.xs_bytes + (unsigned)lane * 16u;
-            f32x16 acc[UT];
-            auto zero_acc = [&]() {
-#pragma unroll
-                for (int ut = 0; ut < UT; ++ut)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[ut][e] = 0.f;
-            };
-            // K slice of wave w: k tiles [w*KH, (w+1)*KH) of the h part, [H/16 + w*KC, ...) of the ctx part
-            auto gemm_part = [&](int rt, int kt0, int i0, auto nk) {
-                constexpr int NK = decltype(nk)::value;
-                const int rtg = min(rg * RT + rt, G.MT - 1);
-                u32x4 af[NK > 0 ? NK : 1];
-#pragma unroll
-                for (int i = 0; i < NK; ++i)
-                    af[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xl + (unsigned)(((kt0 + i) * G.MT + rtg) * 1024), 0, SC1);
-#pragma unroll
-                for (int i = 0; i < NK; ++i)
-#pragma unroll
-                    for (int ut = 0; ut < UT; ++ut)
-                        acc[ut] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]), W[ut][i0 + i], acc[ut], 0, 0, 0);
-            };
-            // one row tile at a time keeps a single set of accumulators live; with one row tile per item the h part runs
-            // before the wait for the contexts (it only needs h_{t-1}, which the attention phase has long had)
-            if (RT == 1) { zero_acc(); gemm_part(0, wave * KH, 0, std::integral_constant<int, KH>{}); }
-            T2_CSTAMP(1);
+            if (EARLY) issue_h(t - 1);
             if (KC > 0) {
                 if (wave == 0 && !poll_counter(cntC_L, ep * nA_per_step, d.err, 2u) && lane == 0) *abortw = 1;
                 __syncthreads();
                 if (*abortw) return;
             }
             T2_CSTAMP(2);
+            if (EARLY) mfma_h();
             // ---- fixed-order sum of the 8 K-split partial tiles, gates, cell update, dropout (model.py:340-346, 371-373)
-            float sv[NSLOT][7];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                if (RT > 1) { zero_acc(); gemm_part(rt, wave * KH, 0, std::integral_constant<int, KH>{}); }
-                if (KC > 0) gemm_part(rt, H / 16 + wave * KC, KH, std::integral_constant<int, KC>{});
+                if (!EARLY) { zero_acc(); gemm_part(t - 1, rt, wave * KH, 0, std::integral_constant<int, KH>{}); }
+                if (KC > 0) gemm_part(t - 1, rt, H / 16 + wave * KC, KH, std::integral_constant<int, KC>{});
                 T2_CSTAMP(14);
 #pragma unroll
                 for (int ut = 0; ut < UT; ++ut) {
@@ -382,41 +449,37 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             T2_CSTAMP(4);
             publish(cntH_L);
             T2_CSTAMP(5);
-            // ---- saved activations (backward pass) and the module-level outputs: plain stores, off the critical path
-#ifndef T2_CHAIN_NOSAVE
-#pragma unroll
-            for (int sl = 0; sl < NSLOT; ++sl) {
-                const int tp = 2 * sl + (tv >> 8);
-                const int b = row0 + (tp / UT) * 32 + ((tv & 255) >> 3), u = u0 + (tp % UT) * 8 + (tv & 7);
-                if (tp < NTILE && b < B) {
-                    const long rb = (long)t * B + b;
-                    float* gp = LS.gates + rb * 4 * H + u;
-                    gp[0] = sv[sl][0]; gp[H] = sv[sl][1]; gp[2 * H] = sv[sl][2]; gp[3 * H] = sv[sl][3];
-                    LS.c_new[rb * H + u] = sv[sl][4];
-                    LS.c_out[rb * H + u] = sv[sl][5];
-                    LS.h_out[rb * LS.ldh + u] = sv[sl][6];
-                    LS.h16_out[rb * LS.ldh16 + u] = (__bf16)sv[sl][6];
-                }
-            }
-#endif
-            if (!hasA && t + 1 < d.t1) load_pre(t + 1, tv);
+            // saved activations: issued here, in the slack before the next poll is answered (issuing scattered stores costs
+            // the wave hundreds of cycles; behind the next phase's loads they sat on the critical path: measured +1.2 us/step)
+            store_L_saved(t, tv);
+            if (!hasA && more) load_pre(t + 1, tv);
         }
         // ======================================================================================= A(t)
         if (hasA) {
             const int tid = tv, lane = tid & 63, wave = tid >> 6;
             T2_CSTAMP(6);
-            if (wave == 0 && !poll_counter(cntH_A, (ep + 1) * (unsigned)G.NUG, d.err, 3u) && lane == 0) *abortw = 1;
+            if (wave == 0) {                          // h_t of the item's row group, and (one request) of the L item's for step t+1
+                const bool ok = (EARLY && hasL && more) ? poll_counters2(cntH_A, (ep + 1) * (unsigned)G.NUG, cntH_L, (ep + 1) * (unsigned)G.NUG, d.err, 3u)
+                                                        : poll_counter(cntH_A, (ep + 1) * (unsigned)G.NUG, d.err, 3u);
+                if (!ok && lane == 0) *abortw = 1;
+            }
             __syncthreads();
             if (*abortw) return;
             T2_CSTAMP(7);
-            // ---- query = ordered sum of the unit groups' partials
+            // ---- query = ordered sum of the unit groups' partials.  Request order: query partials (needed now), h fragments
+            // of the next step (needed in a moment), then the stores of finished work, then next step's cold pre-activations.
             {
                 const int pg = tid >> 5, a4 = (tid & 31) * 4;
                 const unsigned qb = (unsigned)((as * G.NRG + arg) * G.NUG) * (unsigned)(32 * RT * A * 4) + (unsigned)((arow * A + a4) * 4);
-                f32x4 accq = {0.f, 0.f, 0.f, 0.f};
                 constexpr int QU = 4;
-                for (int i0 = pg; i0 < G.NUG; i0 += 16 * QU) {
-                    u32x4 pv[QU];
+                u32x4 pv[QU];
+#pragma unroll
+                for (int k = 0; k < QU; ++k)
+                    pv[k] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, qb + (unsigned)min(pg + 16 * k, G.NUG - 1) * (unsigned)(32 * RT * A * 4), 0, SC1);
+                f32x4 accq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < QU; ++k) if (pg + 16 * k < G.NUG) accq += __builtin_bit_cast(f32x4, pv[k]);
+                for (int i0 = pg + 16 * QU; i0 < G.NUG; i0 += 16 * QU) {       // more than 64 unit groups (8 units per item)
 #pragma unroll
                     for (int k = 0; k < QU; ++k)
                         pv[k] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, qb + (unsigned)min(i0 + 16 * k, G.NUG - 1) * (unsigned)(32 * RT * A * 4), 0, SC1);
@@ -426,7 +489,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 *reinterpret_cast<f32x4*>(redL + pg * A + a4) = accq;
                 // the next step's pre-activations (cold HBM rows): requested here, where this wave needs nothing from
                 // memory until the context is published (vector-memory operations complete in order)
-                if (t + 1 < d.t1) load_pre(t + 1, tv);
+                if (more) load_pre(t + 1, tid);
             }
             __syncthreads();
             if (tid < A) {
@@ -556,18 +619,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             T2_CSTAMP(11);
             publish(cntC_A);
             T2_CSTAMP(12);
-#ifndef T2_CHAIN_NOSAVE
-            {
-                const long rb = (long)t * B + ab_;
-                for (int c = tid; c < EC; c += NTH) {
-                    const float x = csL[c];
-                    d.din[rb * d.WD + AS.coff + c0 + c] = x;
-                    d.dout[rb * d.WO + AS.ctx2off + c0 + c] = x;
-                    d.din16[rb * d.WD + AS.coff + c0 + c] = (__bf16)x;
-                }
-            }
-#endif
-            T2_CSTAMP(13);
+            store_A_saved(t, tid);
         }
     }
 #ifdef T2_STAMPS
