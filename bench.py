@@ -13,11 +13,21 @@ with --gpus N: configs[2] (data parallel over RCCL, weak scaling, one process pe
 decode_steps_per_sec), --workload gta = configs[4] (teacher-forced forward under no_grad, eval, B=128/GPU; replicas
 only, no collective).  The default train line also carries a short "decode" measurement (N=1).
 
-Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     dominant decoder kernel: algorithmic FLOPs per launch / its average duration,
-               measured with HIP events on the launch stream in one extra (untimed) profiled step
-  cpu_baseline the CPU oracle (torch-CPU restatement of the reference, oracle/) timed on this
-               box's host cores on a bounded sample of the same workload (rank 0, N=1 only)
+`--gpus N` without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself — fresh processes, before
+anything touches a GPU, as the reference's distributed.py:181-200 does — and rank 0 prints the line.
+
+Rank 0 prints ONE JSON line.  Extra objects (N = 1 unless noted):
+  roofline      dominant decoder kernel: algorithmic bytes (or FLOPs) per launch / its average duration, measured with
+                HIP events on the launch stream in one extra (untimed) profiled step
+  fresh_batches the same loop fed like train.py:293-316: every step takes the next of 4 pre-collated ragged host batches
+                through data_utils.batch_to_device (pinned staging, H2D) and parse_batch (two .item() syncs)
+  fp32          the parity mode (exact fp32 GEMMs everywhere) on the same batch, a short leg
+  bf16_error    max-abs difference of mel / gate / alignments between the two modes on the bench batch (eval forward)
+  decode        BASELINE configs[3]: inference() at B=32, 1000 decoder steps, stop rule disabled
+  gta           BASELINE configs[4]: teacher-forced forward, eval, no_grad, B=128
+  cpu_baseline  the CPU oracle (torch-CPU restatement of the reference, oracle/) timed on this box's host cores on a
+                bounded sample of the same workload
+  rccl_world_size (every N) the size of the process group the ranks formed (backend nccl = RCCL), 1 without one
 """
 import argparse
 import json
@@ -54,7 +64,11 @@ def decoder_step_bytes(hp, B, Tin, Tsub, wbytes=4):
     att = 2 * (4 * Ha * (E + Ha) * wbytes + A * Ha * 4) + 2 * B * ((E + Ha) * wbytes + (4 * Ha + 4 * Ha + 3 * Ha + Ha // 8 * A) * 4)
     dec = 4 * Hd * Hd * wbytes + B * (Hd * wbytes + (4 * Hd + 4 * Hd + 3 * Hd) * 4)
     attn = B * (Tin + Tsub) * (E + A) * 4
+    # chain_*: one persistent launch covers `steps` steps; its algorithmic bytes are the per-step figures above times the
+    # steps (SURVEY.md section 8d counts what must move if nothing stays on chip between steps — the launch keeps the
+    # weights in registers, so its HBM-side traffic is far below this figure; that is the point of it)
     return dict(att_lstm_fwd=att, dec_lstm_fwd=dec, attention_fwd=attn, attention_bwd=2 * attn,
+                chain_a_fwd_per_step=att + attn, chain_b_fwd_per_step=dec,
                 att_lstm_bwd_gemm=2 * (4 * Ha * (E + Ha) + B * 4 * Ha) * wbytes + 2 * 8 * B * (E + Ha) * 4,
                 dec_lstm_bwd_gemm=(4 * Hd * Hd + B * 4 * Hd) * wbytes + 8 * B * Hd * 4)
 
@@ -183,6 +197,41 @@ def side_workload(a, rank, world, local):
     print(json.dumps(out), flush=True)
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh processes (one per GPU, env:// rendezvous
+    on 127.0.0.1) BEFORE this process has touched a GPU — the job of the reference's distributed.py:181-200 — and exit
+    with the worst return code.  Rank 0 inherits stdout and prints the JSON line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p_ in procs:
+        rc = max(rc, abs(p_.wait()))
+    raise SystemExit(rc)
+
+
+def host_batches(T, hp, B, Tin, Tsub, Tn, n, seed):
+    """n ragged host batches in collate_fn's layout (data_utils.py:98-133 dict keys and dtypes), as a loader step yields."""
+    out = []
+    for i in range(n):
+        text, il, ilb, mel, gate, ol, sub, pcls, bcls, _ = T.synthetic_batch(hp, B, Tin, Tsub, Tn, seed=seed + 17 * i)
+        d = dict(text=text.numpy(), mel_target=mel.transpose(1, 2).contiguous().numpy(), stop_token=gate.double().numpy(),
+                 bert_embeddings=sub.numpy(), bert_embeddings_cls=bcls, phoneme_embeddings_cls=pcls,
+                 length_mel=ol.double().numpy(), length_text=il.double().numpy(), length_bert=ilb.double().numpy())
+        d["align"] = d["text"]
+        out.append(d)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,23 +246,31 @@ def main():
                     help="sma = the reference's default hparams (StepwiseMonotonicAttention); lsa = LocationSensitiveAttention; "
                          "fa2 / gmm / dca = ForwardAttentionV2 / GMMAttention / DynamicConvolutionAttention")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="train workload: only the timed loop and the roofline (no fresh-batch, "
+                                                             "fp32, decode, gta legs)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16",
                     help="GEMM operand type: f32 = exact fp32 (parity path); bf16 = bf16 operands, fp32 accumulate/state")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a.gpus)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", rank))
     if world != a.gpus:
-        if a.gpus != 1 and world == 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+    ndev = max(torch.cuda.device_count(), 1)
+    if world > ndev:
+        # several ranks on one GPU (a rehearsal): the persistent chain kernels need the whole device to themselves
+        os.environ["T2_CHAIN"] = "0"
+    torch.cuda.set_device(local % ndev)
     if a.workload != "train":
         return side_workload(a, rank, world, local)
     a.batch, a.frames = a.batch or 64, a.frames or 400
 
     from tacotron2_subword_amd import _lib as L
+    from tacotron2_subword_amd import data_utils as D
     from tacotron2_subword_amd.hparams import create_hparams
     from tacotron2_subword_amd import train as T
 
@@ -221,9 +278,11 @@ def main():
     hp = create_hparams()
     hp.attention = ATTENTION_NAMES[a.attention]
     hp.distributed_run = world > 1
+    backend = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend=os.environ.get("T2_DIST_BACKEND", "nccl"), init_method="env://", world_size=world, rank=rank)
+        backend = os.environ.get("T2_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
     model, optimizer, criterion = T.make_training_objects(hp)
     model.train()
     B, Tin, Tsub, Tn = a.batch, a.tin, a.tsub, a.frames
@@ -251,6 +310,28 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     loss_val = float(loss.item())
+    extras = world == 1 and not a.no_extras
+
+    # the same loop fed from the host, as train.py:293-316 feeds it: next ragged host batch -> pinned staging -> H2D ->
+    # parse_batch (its two .item() syncs included); 4 pre-collated batches in rotation
+    fresh = None
+    if extras:
+        hb = host_batches(T, hp, B, Tin, Tsub, Tn, 4, seed=4321)
+        for i in range(2):
+            xf, yf = model.parse_batch(D.batch_to_device(hb[i % 4]))
+            T.train_step(model, criterion, optimizer, xf, yf, hp, it)
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        for i in range(a.steps):
+            xf, yf = model.parse_batch(D.batch_to_device(hb[i % 4]))
+            T.train_step(model, criterion, optimizer, xf, yf, hp, it)
+        torch.cuda.synchronize()
+        dtf = time.perf_counter() - tf0
+        fresh = dict(ms_per_step=round(1e3 * dtf / a.steps, 2), value=round(B * Tn * a.steps / dtf, 1), unit="mel-frames/s",
+                     host_batches=4, bytes_per_batch=int(sum(v.numel() * v.element_size() if torch.is_tensor(v) else v.nbytes
+                                                             for k, v in hb[0].items() if k != "align")),
+                     note="every step: data_utils.batch_to_device (pinned staging + non-blocking H2D of the next ragged host batch) "
+                          "+ parse_batch (.item() syncs) + the training iteration; PCIe-inclusive, never `value`")
 
     # one extra, untimed, profiled step: HIP events around every per-step decoder kernel launch
     roof, kernels = None, None
@@ -262,40 +343,56 @@ def main():
         torch.cuda.synchronize()
         bf = a.dtype == "bf16"
         fl, by = decoder_step_flops(hp, B, Tin, Tsub), decoder_step_bytes(hp, B, Tin, Tsub, 2 if bf else 4)
+        by["chain_a_fwd"] = by["chain_a_fwd_per_step"] * Tn          # one launch = all Tn steps
+        by["chain_b_fwd"] = by["chain_b_fwd_per_step"] * Tn
         kernels = {}
         for k, (ms, n) in prof.items():
             if n == 0:
                 continue
             avg_us = 1e3 * ms / n
             e = dict(launches=n, avg_us=round(avg_us, 2), total_ms=round(ms, 2))
+            if k.startswith("chain_"):
+                e["steps_per_launch"] = Tn
+                e["us_per_step"] = round(avg_us / Tn, 2)
             if k in fl:
                 e["tflops"] = round(fl[k] / (avg_us * 1e-6) / 1e12, 2)
             if k in by:
                 e["gbs"] = round(by[k] / (avg_us * 1e-6) / 1e9, 1)
             kernels[k] = e
         dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
-        traffic = None                      # HBM-side bytes per launch from the committed rocprofv3 PMC passes
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-        tkey = {"att_lstm_fwd": "lstm_step_fwd_bf16_grid131072", "dec_lstm_fwd": "lstm_step_fwd_bf16_grid65536",
-                "attention_fwd": "attention_step_fwd_grid131072", "attention_bwd": "attention_step_bwd_grid131072",
-                "att_lstm_bwd_gemm": "lstm_bwd_gemm_bf16_grid393216", "dec_lstm_bwd_gemm": "lstm_bwd_gemm_bf16_grid131072",
-                "att_lstm_bwd_pointwise": "lstm_bwd_pointwise_q_grid65536", "dec_lstm_bwd_pointwise": "lstm_bwd_pointwise_grid65536"}.get(dom)
-        if not bf or a.attention != "sma":
-            tkey = None                     # the committed PMC passes were taken in the default mode (bf16 operands, SMA)
-        if os.path.exists(tpath) and tkey and (B, Tin, Tsub) == (64, 100, 60):
-            traffic = json.load(open(tpath)).get(tkey, {}).get("hbm_bytes_per_launch")
+        # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this round (separate --pmc passes, gfx950
+        # corrections: profiles/README.md); static, not measured in this run
+        traffic, traffic_source = None, None
+        for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", name)
+            tkey = {"att_lstm_fwd": "lstm_step_fwd_bf16_grid131072", "dec_lstm_fwd": "lstm_step_fwd_bf16_grid65536",
+                    "attention_fwd": "attention_step_fwd_grid131072", "attention_bwd": "attention_step_bwd_grid131072",
+                    "att_lstm_bwd_gemm": "lstm_bwd_gemm_bf16_grid393216", "dec_lstm_bwd_gemm": "lstm_bwd_gemm_bf16_grid131072",
+                    "att_lstm_bwd_pointwise": "lstm_bwd_pointwise_q_grid65536", "dec_lstm_bwd_pointwise": "lstm_bwd_pointwise_grid65536",
+                    "chain_a_fwd": "chain_fwd_sma", "chain_b_fwd": "chain_fwd_lstm", "chain_a_bwd": "chain_bwd_sma",
+                    "chain_b_bwd": "chain_bwd_lstm"}.get(dom)
+            if not bf or a.attention != "sma" or (B, Tin, Tsub) != (64, 100, 60) or not tkey or not os.path.exists(tpath):
+                continue
+            ent = json.load(open(tpath)).get(tkey)
+            if ent:
+                traffic = ent.get("hbm_bytes_per_launch")
+                if traffic is not None and ent.get("steps_per_launch") and ent["steps_per_launch"] != Tn:
+                    traffic = traffic * Tn / ent["steps_per_launch"]
+                traffic_source = f"profiles/{name} (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not measured in this run)"
+                break
         # fp32 operands: the recurrent step GEMMs sit just above the fp32-MFMA ridge (AI ~ 26 FLOP/B vs 20) -> MFMA bound;
         # bf16 operands: 16x the matrix rate -> every per-step kernel is bound by operand delivery (HBM / L2)
         if dom in fl and not bf:
             roof = dict(kernel=dom, bound="mfma", achieved=kernels[dom]["tflops"], peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(kernels[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
+                        frac=round(kernels[dom]["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,
                         note="fp32 MFMA (v_mfma_f32_32x32x2_f32) peak; algorithmic FLOPs per launch / avg HIP-event duration")
         else:
-            roof = dict(kernel=dom, bound="hbm", achieved=kernels[dom]["gbs"], peak=PEAK_HBM_GBS, unit="GB/s",
-                        frac=round(kernels[dom]["gbs"] / PEAK_HBM_GBS, 4), traffic=traffic,
-                        note="algorithmic bytes per launch (DESIGN.md section 3) / avg HIP-event duration; the events bracket the "
-                             "launch, so ~3 us of dispatch gap is included (rocprofv3 kernel durations in profiles/ are that "
-                             "much shorter); traffic = HBM-side bytes per launch from the PMC passes in profiles/")
+            roof = dict(kernel=dom, bound="hbm", achieved=kernels[dom].get("gbs"), peak=PEAK_HBM_GBS, unit="GB/s",
+                        frac=round(kernels[dom].get("gbs", 0.0) / PEAK_HBM_GBS, 4), traffic=traffic, traffic_source=traffic_source,
+                        note="algorithmic bytes per launch (DESIGN.md section 3; a persistent chain launch = its per-step figure x the "
+                             "steps it covers) / avg HIP-event duration; the events bracket the launch, so a few us of dispatch gap are "
+                             "included; traffic = HBM-side bytes per launch from the PMC passes in profiles/ — a persistent chain keeps "
+                             "weights, state and memory on chip, so its traffic is far below its algorithmic bytes")
     if world > 1:
         torch.distributed.barrier()
     if rank != 0:
@@ -311,19 +408,71 @@ def main():
                    "hip_kernels": "embeddings, encoder conv/BN + BiLSTM, converters, decoder (prenets, attention LSTMs, SMA, "
                                   "decoder LSTM, projections), postnet conv/BN: forward and backward; gradient-norm clip + Adam",
                    "torch_ops": "loss reductions, cat/transpose copies",
+                   "persistent_chains": bool(L.get_chain()),
                    "precision": ("bf16 operands / fp32 accumulate for every GEMM (hoisted LSTM input halves, per-step recurrent "
                                  "LSTM GEMMs via bf16 weight/activation shadows, convolutions, projections, weight gradients); "
                                  "LSTM gates/state, BatchNorm statistics, attention energies/recurrences, master weights, "
-                                 "gradients and Adam fp32") if a.dtype == "bf16" else "fp32 everywhere (the parity path)"},
+                                 "gradients and Adam fp32") if a.dtype == "bf16" else "fp32 everywhere (the parity path)",
+                   "recurrent_steps_bf16": bool(a.dtype == "bf16" and B <= 128)},
+        "rccl_world_size": torch.distributed.get_world_size() if world > 1 else 1, "dist_backend": backend,
         "loss": round(loss_val, 5),
         "roofline": roof, "kernels": kernels,
     }
-    if world == 1:
-        # "decode steps/sec" half of BASELINE.json's metric: a bounded run of configs[3] (B=32, stop disabled)
-        out["decode"] = decode_bench(model, hp, 32, Tin, Tsub, steps=250, reps=2)
+    if a.dtype == "bf16" and B > 128:
+        out["config"]["note"] = "B > 128: the recurrent per-step GEMMs fall back to fp32 operands (bf16 steps cover B <= 128)"
+    if fresh is not None:
+        out["fresh_batches"] = fresh
+    if extras and a.dtype == "bf16":
+        # parity mode on the same batch + how far the bf16 mode's outputs sit from it (eval forward, dropout off)
+        def eval_outputs():
+            model.eval()
+            model.decoder.prenet_dropout = False
+            with torch.no_grad():
+                o = model(x)
+            model.decoder.prenet_dropout = True
+            model.train()
+            return [t.float().clone() for t in o]
+        o16 = eval_outputs()
+        L.set_precision("f32")
+        o32 = eval_outputs()
+        names = ("mel", "mel_postnet", "gate", "align", "align_bert")
+        out["bf16_error"] = {n: round(float((p - q).abs().max()), 5) for n, p, q in zip(names, o16, o32)}
+        out["bf16_error"]["note"] = "max-abs, bf16-operand mode vs fp32 mode (both HIP), eval forward of the bench batch after the timed steps"
+        T.train_step(model, criterion, optimizer, x, y, hp, it)
+        torch.cuda.synchronize()
+        n32 = max(2, min(a.steps, 3))
+        t32 = time.perf_counter()
+        for _ in range(n32):
+            T.train_step(model, criterion, optimizer, x, y, hp, it)
+        torch.cuda.synchronize()
+        d32 = (time.perf_counter() - t32) / n32
+        out["fp32"] = dict(ms_per_step=round(1e3 * d32, 2), value=round(B * Tn / d32, 1), unit="mel-frames/s", steps=n32,
+                           note="t2_set_precision(0): exact fp32 GEMMs everywhere — the mode the 1e-4 parity contract is tested in")
+        L.set_precision(a.dtype)
+    if extras:
+        # "decode steps/sec" half of BASELINE.json's metric: configs[3] (B=32, 1000 decoder steps, stop disabled)
+        out["decode"] = decode_bench(model, hp, 32, Tin, Tsub, steps=1000, reps=2)
+        out["gta"] = gta_bench(model, hp, T, 128, Tin, Tsub, Tn, reps=3)
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)
+
+
+def gta_bench(model, hp, T, B, Tin, Tsub, Tn, reps):
+    """BASELINE configs[4]: teacher-forced forward, eval mode, no_grad, B=128 per GPU (GTA.py:57-59)."""
+    was = model.training
+    model.eval()
+    x, _ = model.parse_batch(T.synthetic_batch(hp, B, Tin, Tsub, Tn, seed=99))
+    with torch.no_grad():
+        model(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            model(x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+    model.train(was)
+    return dict(batch=B, frames=Tn, ms_per_forward=round(1e3 * dt, 2), frames_per_sec=round(B * Tn / dt, 1))
 
 
 if __name__ == "__main__":

@@ -84,6 +84,9 @@ typedef struct t2_dims {
     int n_streams;      /* 2 = BERT_Tacotron2 (phone + sub-word, model.py:142-207); 1 = classic single-stream Tacotron2
                            (the API GTA.py:6,57-59 expects): decoder_rnn takes [att_h|ctx], projections [dec_h|ctx];
                            the *_sub weights / memory_sub / align_sub are then ignored (0 is read as 2) */
+    float score_mask_value, score_mask_value_sub; /* energy written over positions past an item's length: the attention
+                           modules' score_mask_value (attention.py:37,79; train.py:77-78 sets the phone stream's to the fp16
+                           minimum for fp16 runs).  0 = the default, -infinity */
 } t2_dims;
 
 /* Parameters of Decoder (model.py:128-207), reference state_dict names in comments. */
@@ -317,12 +320,16 @@ int t2_mask_btc(float* x, int B, int T, int C, const int32_t* lengths, float fil
  * torch.optim.Adam.step of the training loop (train.py:322-330; Adam with weight decay added to the gradient).
  * `table` is a DEVICE array of n_tensors rows; row i covers chunks [first_chunk, first_chunk + t2_adam_chunks(numel))
  * and the rows are sorted by first_chunk (consecutive).  partial: n_chunks floats of scratch; norm_out: 2 floats
- * (total gradient norm, clip coefficient applied).  max_norm <= 0 disables clipping.  step counts from 1.
- * Gradients are read, not modified (the coefficient is applied on the fly). */
+ * (total gradient norm, clip coefficient applied).  max_norm == 0 disables clipping.  step counts from 1.
+ * Gradients are read, not modified (the coefficient is applied on the fly).
+ * Parameters whose step counts differ (torch.optim.Adam corrects the bias per parameter): t2_adam_norm over the whole
+ * table first, then one t2_adam_step per run of rows with equal step, with max_norm < 0 (= take the coefficient
+ * t2_adam_norm left in norm_out[1]), `table` pointing at the run's first row and n_chunks = the run's chunk count. */
 typedef struct t2_adam_tensor { float* p; const float* g; float* m; float* v; long numel; int first_chunk; int pad_; } t2_adam_tensor;
 int t2_adam_chunks(long numel);
 int t2_adam_step(const t2_adam_tensor* table, int n_tensors, int n_chunks, float* partial, float* norm_out, float max_norm,
                  float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+int t2_adam_norm(const t2_adam_tensor* table, int n_tensors, int n_chunks, float* partial, float* norm_out, float max_norm, void* stream);
 
 /* In-situ kernel timing for bench.py's roofline figures: after t2_prof_enable(n) the decoder
  * drivers bracket each per-step kernel launch with HIP events on the launch stream (up to n

@@ -27,7 +27,8 @@ class Dims(C.Structure):
     _fields_ = [("n_mel", C.c_int), ("prenet_dim", C.c_int), ("enc_dim", C.c_int), ("att_rnn_dim", C.c_int),
                 ("dec_rnn_dim", C.c_int), ("att_dim", C.c_int), ("loc_filters", C.c_int), ("loc_kernel", C.c_int),
                 ("attention_kind", C.c_int), ("p_att_dropout", C.c_float), ("p_dec_dropout", C.c_float),
-                ("p_prenet_dropout", C.c_float), ("n_streams", C.c_int)]
+                ("p_prenet_dropout", C.c_float), ("n_streams", C.c_int),
+                ("score_mask_value", C.c_float), ("score_mask_value_sub", C.c_float)]
 
 
 class AttentionWeights(C.Structure):
@@ -150,7 +151,7 @@ class GemmArgs(C.Structure):
 
 # every symbol include/t2amd.h declares (tests/test_abi.py checks the library exports them all)
 EXPORTS = ["t2_last_error", "t2_version", "t2_set_precision", "t2_get_precision", "t2_set_overlap", "t2_set_chain", "t2_get_chain", "t2_set_gemm_staging", "t2_side_join", "t2_decoder_layout_query", "t2_decoder_forward", "t2_decoder_infer",
-           "t2_decoder_bwd_layout_query", "t2_decoder_backward", "t2_prof_enable", "t2_prof_collect", "t2_adam_chunks", "t2_adam_step",
+           "t2_decoder_bwd_layout_query", "t2_decoder_backward", "t2_prof_enable", "t2_prof_collect", "t2_adam_chunks", "t2_adam_step", "t2_adam_norm",
            "t2_conv_bn_forward", "t2_conv_bn_backward", "t2_embedding_forward", "t2_embedding_backward",
            "t2_lstm_seq_forward", "t2_lstm_seq_backward", "t2_gemm_ex", "t2_colsum", "t2_mask_btc",
            "t2_finalize_bct", "t2_mask_bt", "t2_gemm", "t2_rng_keep_mask", "t2_rng_normal"]

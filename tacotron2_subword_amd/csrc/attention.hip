@@ -232,7 +232,7 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
         const RngKey key = rng_key(d.seed, st.site_noise);
         for (int j = tid; j < Tin; j += NT) {
             float ev = e[j];
-            if (j >= len) ev = d.mask_value;
+            if (j >= len) ev = st.mask_value;
             if (d.noise_std > 0.f) ev += d.noise_std * rng_normal(key, st.idx_base + (uint32_t)b * st.idx_bstride + (uint32_t)j);
             const float p = sigmoidf_(ev);
             e[j] = p;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(NT) void attention_step_fwd_kernel(AttnStepDesc d) 
         float mx = -INFINITY;
         for (int j = tid; j < Tin; j += NT) {
             float ev = e[j];
-            if (j >= len) ev = d.mask_value;
+            if (j >= len) ev = st.mask_value;
             e[j] = ev;
             mx = fmaxf(mx, ev);
         }
@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(NT) void attention_gmm_step_fwd_kernel(AttnStepDesc
             const float dj = (float)j - par[8 + k];
             phi += par[k] * expf(-(dj * dj) / par[16 + k] / 2.0f);
         }
-        if (j >= len) phi = d.mask_value;
+        if (j >= len) phi = st.mask_value;
         e[j] = phi;
         mx = fmaxf(mx, phi);
     }
@@ -1459,7 +1459,7 @@ __global__ __launch_bounds__(NT) void attention_dca_step_fwd_kernel(AttnStepDesc
     float mx = -INFINITY;
     for (int j = tid; j < Tin; j += NT) {
         float ev = e[j];
-        if (j >= len) ev = d.mask_value;
+        if (j >= len) ev = st.mask_value;
         e[j] = ev;
         mx = fmaxf(mx, ev);
     }

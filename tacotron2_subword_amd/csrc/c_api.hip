@@ -147,6 +147,12 @@ t2_dims canon_dims(const t2_dims& in, int* max_pos) {
 
 size_t align4(size_t n) { return (n + 3) & ~(size_t)3; }
 
+// score_mask_value of the stream's attention module; a zero-initialised t2_dims (0.0) means the default, -inf
+float mask_value_of(const t2_dims& d, int stream) {
+    const float v = stream ? d.score_mask_value_sub : d.score_mask_value;
+    return v == 0.f ? -INFINITY : v;
+}
+
 // Decode loop, bf16-operand mode: whole-cell weight shadows [W_hh | W_ih[:,P:] | W_ih[:,:P]] (attention LSTMs) and
 // [W_ih | W_hh] (decoder LSTM) so that each cell is ONE K-contiguous product, plus the bf16 input rows the producing
 // kernels write: att rows [2][NS][B][Ha+E+P] = [h | ctx | prenet], dec rows [2][B][WD+Hd] = [att_h | ctx | ... | dec_h],
@@ -351,7 +357,6 @@ int attention_step(const Dec& c, int t) {
     d.nstreams = z.NS; d.B = z.B; d.A = z.A; d.E = z.E; d.kind = c.d.attention_kind;
     d.F = c.d.loc_filters; d.Kc = c.d.loc_kernel; d.seed = c.seed; d.first = t == 0;
     d.noise_std = (c.training && d.kind == T2_ATTN_SMA) ? 2.0f : 0.f;     // attention.py:315,346-348
-    d.mask_value = -INFINITY;                                              // attention.py:37,306
     d.max_pos = c.max_pos;
     for (int s = 0; s < z.NS; ++s) {
         AttnStream& st = d.st[s];
@@ -387,6 +392,7 @@ int attention_step(const Dec& c, int t) {
         } else if (c.use16) { st.ctx16 = c.P16(L.din16) + c.R(t) * z.WD + ((s ? z.Ha + z.E : 0) + z.Ha); st.ldctx16 = z.WD; }
         st.v = aw.v; st.loc_conv = aw.loc_conv; st.loc_dense = aw.loc_dense;
         st.site_noise = s ? T2_SITE_NOISE_SUB : T2_SITE_NOISE;
+        st.mask_value = mask_value_of(c.d, s);                              // attention.py:37,79 / train.py:77-78
         st.idx_base = (uint32_t)(c.R(t) * Tin); st.idx_bstride = (uint32_t)Tin;          // logical [T,B,Tin]
     }
     if (d.kind == T2_ATTN_GMM) d.kind = 2;                       // kernel-level kind (0 SMA, 1 LSA, 2 GMM, 3 DCA)
@@ -445,7 +451,7 @@ bool chain_a_desc(const Dec& c, ChainDesc* out) {
     d.NS = z.NS; d.B = z.B; d.T = z.T; d.H = z.Ha; d.E = z.E; d.A = z.A; d.WD = z.WD; d.WO = z.WO;
     d.din = c.P(L.din); d.din16 = c.P16(L.din16); d.dout = c.P(L.dout);
     d.kind = c.d.attention_kind == T2_ATTN_SMA ? CHAIN_SMA : CHAIN_LSA;
-    d.F = c.d.loc_filters; d.Kc = c.d.loc_kernel; d.max_pos = c.max_pos; d.mask_value = -INFINITY;
+    d.F = c.d.loc_filters; d.Kc = c.d.loc_kernel; d.max_pos = c.max_pos;
     d.drop_p = c.training ? c.d.p_att_dropout : 0.f;
     d.noise_std = (c.training && d.kind == CHAIN_SMA) ? 2.0f : 0.f;
     d.seed = c.seed;
@@ -465,6 +471,7 @@ bool chain_a_desc(const Dec& c, ChainDesc* out) {
         st.v = aw.v; st.loc_conv = aw.loc_conv; st.loc_dense = aw.loc_dense;
         st.site_h = s ? T2_SITE_ATT_H_SUB : T2_SITE_ATT_H; st.site_c = s ? T2_SITE_ATT_C_SUB : T2_SITE_ATT_C;
         st.site_noise = s ? T2_SITE_NOISE_SUB : T2_SITE_NOISE;
+        st.mask_value = mask_value_of(c.d, s);
     }
     if (!chain_plan(d)) return false;
     const ChainBufs b = chain_bufs(z, L, c.ws);
@@ -1364,6 +1371,10 @@ int t2_adam_step(const t2_adam_tensor* table, int n_tensors, int n_chunks, float
     static_assert(sizeof(t2_adam_tensor) == sizeof(AdamTensor), "table row layout");
     return adam_step(reinterpret_cast<const AdamTensor*>(table), n_tensors, n_chunks, partial, norm_out, max_norm, lr, beta1, beta2, eps,
                      weight_decay, step, (hipStream_t)stream);
+}
+
+int t2_adam_norm(const t2_adam_tensor* table, int n_tensors, int n_chunks, float* partial, float* norm_out, float max_norm, void* stream) {
+    return adam_norm(reinterpret_cast<const AdamTensor*>(table), n_tensors, n_chunks, partial, norm_out, max_norm, (hipStream_t)stream);
 }
 
 int t2_finalize_bct(const float* in_btc, float* out_bct, int B, int T, int C, const int32_t* lengths, float fill, void* stream) {

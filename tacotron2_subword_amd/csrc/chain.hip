@@ -556,8 +556,8 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             T2_CSTAMP(9);
             if (KIND == CHAIN_SMA) {
                 // p = sigmoid(e + noise) ; a_t[j] = a_{t-1}[j] p_j + a_{t-1}[j-1] (1 - p_{j-1})      (attention.py:337-348)
-                float maskv = d.mask_value;
-                asm volatile("" : "+v"(maskv));             // opaque: otherwise hipcc selects between &eL[j] and &d.mask_value and reads through flat_load
+                float maskv = AS.mask_value;
+                asm volatile("" : "+v"(maskv));             // opaque: otherwise hipcc selects between &eL[j] and &mask_value and reads through flat_load
                 for (int j = tid; j < Tin; j += NTH) {
                     float ev = eL[j];
                     if (j >= alen) ev = maskv;

@@ -137,11 +137,12 @@ struct AttnStream {
     const float* gmm_b1; const float* gmm_w2; const float* gmm_b2;   // [A], [3K, A], [3K]
     const float* mu_prev; float* mu_out;  // [B, kGmmPad] mixture means before / after this step (mu_prev null at t=0 -> 0)
     DcaWeights dca;                       // kind 3
+    float mask_value;                     // energy of positions past the item's length (the module's score_mask_value)
 };
 constexpr int kGmmK = 5, kGmmPad = 8;     // mixtures (attention.py:409), row pitch of the mean buffers
 struct AttnStepDesc {
     AttnStream st[2]; int nstreams; int B, A, E; int kind;   // kind 0 = SMA, 1 = LSA
-    int F, Kc; float noise_std; uint64_t seed; float mask_value; int first;   // kind 2 = GMM (attention_gmm_step_fwd)
+    int F, Kc; float noise_std; uint64_t seed; int first;                     // kind 2 = GMM (attention_gmm_step_fwd)
     int lsa_pa;                                               // set by the launcher (MFMA path of the LSA dense projection)
     int max_pos;                                              // > 0: valid length clamped to max_pos (ForwardAttentionV2, see c_api.hip)
 };
@@ -200,12 +201,13 @@ struct ChainStream {
     float* align; float* psel; float* wcum; float* qs;                   // [B,T,Tin] x3, [T,B,A]
     const float* v; const float* loc_conv; const float* loc_dense;
     uint32_t site_h, site_c, site_noise;
+    float mask_value;                     // energy of positions past the item's length
 };
 struct ChainDesc {
     ChainStream st[2]; int NS, B, T, t0, t1;
     int H, E, A, WD, WO;
     float* din; __bf16* din16; float* dout;        // [T][B][WD] (fp32 + bf16 shadow), [T][B][WO]
-    int kind, F, Kc, max_pos; float mask_value;
+    int kind, F, Kc, max_pos;
     float drop_p, noise_std; uint64_t seed;
     unsigned char* X; float* Q; unsigned* cnt; unsigned* err; unsigned q_bytes;   // exchange buffers (chain_exchange_bytes)
     int UT, RT, CS;                                // tiling chosen by chain_plan
@@ -265,6 +267,7 @@ int embedding_bwd(const long* ids, const float* dout, float* dtable, int rows, i
 // ------------------------------------------------------------------ optimizer (optim.hip)
 struct AdamTensor { float* p; const float* g; float* m; float* v; long numel; int first_chunk; int pad_; };   // 48 bytes, mirrors t2_adam_tensor
 int adam_chunks(long numel);
+int adam_norm(const AdamTensor* table_dev, int n_tensors, int n_chunks, float* partial, float* norm_out, float max_norm, hipStream_t s);
 int adam_step(const AdamTensor* table_dev, int n_tensors, int n_chunks, float* partial, float* norm_out, float max_norm,
               float lr, float b1, float b2, float eps, float wd, int step, hipStream_t s);
 

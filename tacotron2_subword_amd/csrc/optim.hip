@@ -65,7 +65,7 @@ __global__ __launch_bounds__(1024) void norm_finish_kernel(const float* __restri
 
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTensor* __restrict__ tab, int n, const float* __restrict__ coef,
                                                    float lr_over_bc1, float inv_sqrt_bc2, float b1, float b2, float eps, float wd) {
-    const int chunk = blockIdx.x;
+    const int chunk = blockIdx.x + tab[0].first_chunk;       // a sub-table (rows of one step count) starts at its own first chunk
     const AdamTensor t = tab[find_tensor(tab, n, chunk)];
     const long off = (long)(chunk - t.first_chunk) * kChunk;
     const long cnt = min((long)kChunk, t.numel - off);
@@ -100,11 +100,20 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTensor* __restrict_
 
 int adam_chunks(long numel) { return (int)((numel + kChunk - 1) / kChunk); }
 
+int adam_norm(const AdamTensor* table_dev, int n_tensors, int n_chunks, float* partial, float* norm_out, float max_norm, hipStream_t s) {
+    T2_REQUIRE(table_dev && n_tensors >= 1 && n_chunks >= 1 && partial && norm_out, "adam_norm: bad arguments");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(256), 0, s, table_dev, n_tensors, partial);
+    hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(1024), 0, s, partial, n_chunks, max_norm, norm_out);
+    T2_LAUNCH_CHECK();
+    return 0;
+}
+
+// max_norm >= 0: norm + clip coefficient over this table, then the update.  max_norm < 0: update only, with the
+// coefficient adam_norm left in norm_out[1]; the table may then be a run of rows of a larger table (n_chunks = its chunks).
 int adam_step(const AdamTensor* table_dev, int n_tensors, int n_chunks, float* partial, float* norm_out, float max_norm,
               float lr, float b1, float b2, float eps, float wd, int step, hipStream_t s) {
     T2_REQUIRE(table_dev && n_tensors >= 1 && n_chunks >= 1 && partial && norm_out && step >= 1, "adam_step: bad arguments");
-    hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(256), 0, s, table_dev, n_tensors, partial);
-    hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(1024), 0, s, partial, n_chunks, max_norm, norm_out);
+    if (max_norm >= 0.f) T2_TRY_RC(adam_norm(table_dev, n_tensors, n_chunks, partial, norm_out, max_norm, s));
     const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(n_chunks), dim3(256), 0, s, table_dev, n_tensors, norm_out,
                        (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), b1, b2, eps, wd);

@@ -18,7 +18,6 @@ import os
 
 import numpy as np
 import torch
-from torch.nn import functional as F
 from torch.utils.data import Dataset
 
 from .utils import create_alignment
@@ -58,26 +57,6 @@ class BERTTacotron2Dataset(Dataset):
         return sample
 
 
-def pad_normal(inputs, PAD=0):
-    max_len = max((len(x) for x in inputs))
-    return np.stack([np.pad(x, (0, max_len - x.shape[0]), mode="constant", constant_values=PAD) for x in inputs])
-
-
-def pad_mel(inputs):
-    def pad(x, max_len):
-        if np.shape(x)[0] > max_len:
-            raise ValueError("not max_len")
-        s = np.shape(x)[1]
-        return np.pad(x, (0, max_len - np.shape(x)[0]), mode="constant", constant_values=0)[:, :s]
-    max_len = max(np.shape(x)[0] for x in inputs)
-    return np.stack([pad(x, max_len) for x in inputs])
-
-
-def pad_emb(inputs):
-    max_len = max(x.size(0) for x in inputs)
-    return torch.stack([F.pad(x, (0, 0, 0, max_len - x.size(0))) for x in inputs])
-
-
 def get_alignment(filename):
     """Hard alignment [T, T_in] from the duration column of a phone file (data_utils.py:135-144)."""
     dur = torch.from_numpy(np.load(filename).astype(int))[:, 1].unsqueeze(0)
@@ -85,83 +64,142 @@ def get_alignment(filename):
     return create_alignment(alignment, dur)[0]
 
 
-def reprocess(batch, cut_list):
-    texts = [batch[ind]["text"] for ind in cut_list]
-    bert_embeddings = [batch[ind]["bert_embedding"] for ind in cut_list]
-    bert_embeddings_cls = [batch[ind]["bert_embedding_cls"] for ind in cut_list]
-    phoneme_embeddings_cls = [batch[ind]["phoneme_embedding_cls"] for ind in cut_list]
-    mel_targets = [batch[ind]["mel_target"] for ind in cut_list]
-    stop_tokens = [batch[ind]["stop_token"] for ind in cut_list]
-    length_text = np.array([float(t.shape[0]) for t in texts])
-    length_bert = np.array([float(e.shape[0]) for e in bert_embeddings])
-    length_mel = np.array([float(m.shape[0]) for m in mel_targets])
-    have_dur = all("duration" in batch[ind] for ind in cut_list)
-    texts = pad_normal(texts)
-    out = {"text": texts, "mel_target": pad_mel(mel_targets), "stop_token": pad_normal(stop_tokens, PAD=1.),
-           "bert_embeddings": pad_normal(bert_embeddings), "bert_embeddings_cls": pad_emb(bert_embeddings_cls),
-           "phoneme_embeddings_cls": pad_emb(phoneme_embeddings_cls), "length_mel": length_mel, "length_text": length_text,
-           "length_bert": length_bert}
-    if have_dur:
+# ---------------------------------------------------------------------------------------------------------------
+# Collation straight into host staging.  One model batch = one _Stage: a flat buffer per field, page-locked when the
+# process has a CUDA context (a DataLoader worker has none: pageable there), written once per batch by the loops below —
+# no per-item pad / stack temporaries — and handed to the GPU by batch_to_device with one non-blocking copy per field.
+# A ring of stages keeps the batches of two loader steps apart, so batch k+1 is collated and uploaded while step k runs;
+# each stage carries the event recorded behind its last upload and is refilled only after that event.
+# ---------------------------------------------------------------------------------------------------------------
+class _Stage:
+    def __init__(self):
+        self.buf, self.event = {}, None
+
+    def wait(self):
+        if self.event is not None:
+            self.event.synchronize()
+            self.event = None
+
+    def take(self, name, shape, dtype, fill=None):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        b = self.buf.get(name)
+        if b is None or b.numel() < n or b.dtype != dtype:
+            b = torch.empty(max(n, 1), dtype=dtype)
+            if torch.cuda.is_available() and torch.cuda.is_initialized():
+                b = b.pin_memory()
+            self.buf[name] = b
+        v = b[:n].view(*shape)
+        if fill is not None:
+            v.fill_(fill)
+        return v
+
+
+class StagedBatch(dict):
+    """A collated model batch (the reference's dict keys) whose arrays live in `stage`."""
+    stage = None
+
+
+class _Ring:
+    def __init__(self):
+        self.stages, self.next = [], 0
+
+    def get(self, per_step):
+        want = max(2 * per_step, 2)                       # the batches of two loader steps
+        while len(self.stages) < want:
+            self.stages.append(_Stage())
+        st = self.stages[self.next % len(self.stages)]
+        self.next += 1
+        st.wait()
+        return st
+
+
+_RING = _Ring()
+
+
+def _collate_cut(batch, cut, stage):
+    """One model batch (data_utils.py:98-133), every field written in place: zero (or pad-value) fill, then one slice
+    assignment per item.  Dtypes and values are those of the reference's pad_normal / pad_mel / pad_emb."""
+    items = [batch[int(i)] for i in cut]
+    n = len(items)
+    n_text = [int(it["text"].shape[0]) for it in items]
+    n_sub = [int(it["bert_embedding"].shape[0]) for it in items]
+    n_mel = [int(it["mel_target"].shape[0]) for it in items]
+    Tin, Tsub, T = max(n_text), max(n_sub), max(n_mel)
+    mel0 = items[0]["mel_target"]
+    text = stage.take("text", (n, Tin), items[0]["text"].dtype, 0)
+    sub = stage.take("sub", (n, Tsub), items[0]["bert_embedding"].dtype, 0)
+    mel = stage.take("mel", (n, T, mel0.shape[1]), torch.from_numpy(mel0[:0]).dtype, 0)
+    stop = stage.take("stop", (n, T), torch.float64, 1.0)
+    C = items[0]["bert_embedding_cls"].shape[1]
+    pcls = stage.take("pcls", (n, Tin, C), items[0]["phoneme_embedding_cls"].dtype, 0)
+    bcls = stage.take("bcls", (n, Tsub, C), items[0]["bert_embedding_cls"].dtype, 0)
+    for k, it in enumerate(items):
+        text[k, :n_text[k]] = it["text"]
+        sub[k, :n_sub[k]] = it["bert_embedding"]
+        mel[k, :n_mel[k]] = torch.from_numpy(np.ascontiguousarray(it["mel_target"]))
+        stop[k, :n_mel[k]] = torch.from_numpy(np.asarray(it["stop_token"], dtype=np.float64))
+        pcls[k, :n_text[k]] = it["phoneme_embedding_cls"]
+        bcls[k, :n_sub[k]] = it["bert_embedding_cls"]
+    lt = stage.take("length_text", (n,), torch.float64)
+    lb = stage.take("length_bert", (n,), torch.float64)
+    lm = stage.take("length_mel", (n,), torch.float64)
+    lt.copy_(torch.tensor(n_text, dtype=torch.float64)); lb.copy_(torch.tensor(n_sub, dtype=torch.float64)); lm.copy_(torch.tensor(n_mel, dtype=torch.float64))
+    out = StagedBatch(text=text.numpy(), mel_target=mel.numpy(), stop_token=stop.numpy(), bert_embeddings=sub.numpy(),
+                      bert_embeddings_cls=bcls, phoneme_embeddings_cls=pcls, length_mel=lm.numpy(), length_text=lt.numpy(),
+                      length_bert=lb.numpy())
+    out.stage = stage
+    if all("duration" in it for it in items):
         # alignloss != "": the reference's collate calls get_alignment(texts) against a (self, filename) signature and
         # raises; what it is after is the padded hard alignment [B, T_max, T_in_max] built from the duration column
-        durs = pad_normal([batch[ind]["duration"].numpy() for ind in cut_list])
-        T = out["mel_target"].shape[1]
-        al = create_alignment(torch.zeros(len(cut_list), max(T, int(durs.sum(1).max())), durs.shape[1]), torch.from_numpy(durs))
-        out["align"] = al[:, :T].numpy()
+        durs = torch.zeros(n, Tin, dtype=items[0]["duration"].dtype)
+        for k, it in enumerate(items):
+            durs[k, :n_text[k]] = it["duration"]
+        al = create_alignment(torch.zeros(n, max(T, int(durs.sum(1).max())), Tin), durs)
+        out["align"] = stage.take("align", (n, T, Tin), al.dtype).copy_(al[:, :T]).numpy()
     else:
-        out["align"] = texts
+        out["align"] = out["text"]
     return out
 
 
 def collate_fn(batch):
-    len_arr = np.array([d["text"].shape[0] for d in batch])
-    index_arr = np.argsort(-len_arr)
-    real_batchsize = int(math.sqrt(len(batch)))
-    cut_list = [index_arr[i * real_batchsize:(i + 1) * real_batchsize] for i in range(real_batchsize)]
-    return [reprocess(batch, cut_list[i]) for i in range(real_batchsize)]
-
-
-class _Stager:
-    """One pinned host buffer per field, grown on demand; copies are non-blocking on the current stream.  An event
-    recorded after a batch's copies guards the buffers against being refilled while those copies are in flight."""
-
-    def __init__(self):
-        self.buf, self.event = {}, None
-
-    def put(self, name, t, dtype, device):
-        t = t if torch.is_tensor(t) else torch.from_numpy(np.ascontiguousarray(t))
-        t = t.to(dtype)
-        if device.type != "cuda":
-            return t.to(device)
-        b = self.buf.get(name)
-        if b is None or b.numel() < t.numel() or b.dtype != dtype:
-            b = torch.empty(max(t.numel(), 1), dtype=dtype).pin_memory()
-            self.buf[name] = b
-        v = b[:t.numel()].view(t.shape)
-        v.copy_(t)
-        return v.to(device, non_blocking=True)
-
-
-_STAGER = _Stager()
+    """data_utils.py:146-206: the loader batch holds batch_size**2 items; sorted by phone count (descending) and cut into
+    batch_size model batches, returned as a list."""
+    order = np.argsort(-np.array([d["text"].shape[0] for d in batch]))
+    per_step = int(math.sqrt(len(batch)))
+    return [_collate_cut(batch, order[i * per_step:(i + 1) * per_step], _RING.get(per_step)) for i in range(per_step)]
 
 
 def batch_to_device(data_of_batch, device="cuda"):
-    """train.py:295-316: one collate_fn batch -> the 10-tuple `BERT_Tacotron2.parse_batch` takes."""
+    """train.py:295-316: one collate_fn batch -> the 10-tuple `BERT_Tacotron2.parse_batch` takes.  Each field goes up
+    as collated (one non-blocking copy out of the batch's page-locked stage, on the current stream); dtype changes and
+    the mel transpose happen on the device.  A batch that did not come out of collate_fn is staged here first."""
     device = torch.device(device)
-    if _STAGER.event is not None:
-        _STAGER.event.synchronize()                      # the previous batch's H2D copies have left the pinned buffers
-    d, put = data_of_batch, _STAGER.put
-    character = put("text", d["text"], torch.long, device)
-    mel_target = put("mel", d["mel_target"], torch.float32, device).contiguous().transpose(1, 2)
-    stop_target = put("stop", d["stop_token"], torch.float32, device)
-    embeddings = put("sub", d["bert_embeddings"], torch.long, device)
-    phoneme_cls = put("pcls", d["phoneme_embeddings_cls"], torch.float32, device)
-    bert_cls = put("bcls", d["bert_embeddings_cls"], torch.float32, device)
-    il = put("il", d["length_text"], torch.long, device)
-    ilb = put("ilb", d["length_bert"], torch.long, device)
-    ol = put("ol", d["length_mel"], torch.long, device)
-    align = put("align", d["align"], torch.long, device)
+    d = data_of_batch
+    stage = getattr(d, "stage", None)
+    own = stage is None
+    if own:
+        stage = _RING.get(1)
+
+    def up(name, dtype):
+        v = d[name]
+        t = v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v))
+        if device.type != "cuda":
+            return t.to(dtype)
+        if not t.is_pinned():
+            t = stage.take("_" + name, tuple(t.shape), t.dtype).copy_(t)
+        return t.to(device, non_blocking=True).to(dtype)
+
+    character = up("text", torch.long)
+    mel_target = up("mel_target", torch.float32).contiguous().transpose(1, 2)
+    stop_target = up("stop_token", torch.float32)
+    embeddings = up("bert_embeddings", torch.long)
+    phoneme_cls = up("phoneme_embeddings_cls", torch.float32)
+    bert_cls = up("bert_embeddings_cls", torch.float32)
+    il, ilb, ol = up("length_text", torch.long), up("length_bert", torch.long), up("length_mel", torch.long)
+    align = character if d["align"] is d["text"] else up("align", torch.long)
     if device.type == "cuda":
-        _STAGER.event = torch.cuda.Event()
-        _STAGER.event.record(torch.cuda.current_stream(device))
+        stage.event = torch.cuda.Event()
+        stage.event.record(torch.cuda.current_stream(device))
     return character, il, ilb, mel_target, stop_target, ol, embeddings, phoneme_cls, bert_cls, align

@@ -62,6 +62,11 @@ class GradArena:
         self.live.add(p)
 
     def reset(self):
+        # the parameters each bucket waits for this step: those known to be live NOW.  A parameter that produces its
+        # first gradient later (a layer unfrozen mid-run) is not in the snapshot: it must not count a bucket down, and
+        # its bucket is reduced by finish() at the end of that backward instead of from a hook.
+        self.counted = set(self.live)
+        self.late = False
         self.pending = [sum(1 for p in b if (not self.live) or p in self.live) for b in self.buckets]
         self.launched = [False] * len(self.buckets)
         self.handles, self.queued = [], False
@@ -115,12 +120,27 @@ def apply_gradient_allreduce(module):
 
     def make_hook(p):
         def hook(_):
+            i = arena.bucket_of[p]
+            newcomer = module.needs_reduction and arena.first_done and p not in arena.counted
+            if newcomer and arena.launched[i]:
+                # first gradient of a parameter nobody waited for, and its bucket is already being reduced: the copy into
+                # the arena must not race with that collective, and the parameter gets a reduction of its own
+                for h in arena.handles:
+                    h.wait()
+                arena.handles = []
+                arena.adopt(p)
+                seg = arena.view(p)
+                seg.mul_(1.0 / world)
+                arena.handles.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
+                return
             arena.adopt(p)
             if not module.needs_reduction:
                 return
-            i = arena.bucket_of[p]
-            arena.pending[i] -= 1
-            if arena.pending[i] == 0 and not arena.launched[i] and arena.first_done:
+            if newcomer:
+                arena.late = True                    # its bucket has not started: finish() reduces it, no more launches from hooks
+            else:
+                arena.pending[i] -= 1
+            if arena.pending[i] == 0 and not arena.launched[i] and arena.first_done and not arena.late:
                 launch(i)
             if not arena.queued:
                 arena.queued = True

@@ -131,16 +131,27 @@ class _DecoderFn(torch.autograd.Function):
                                  training=cfg["training"], prenet_dropout=cfg["prenet_dropout"], seed=cfg["seed"],
                                  dp=None if pre is None else pre["dp"])
         cfg.pop("pre", None)
+        # The outputs leave the pass object: kept on ctx they would close a cycle output -> grad_fn -> ctx -> dp -> output that
+        # runs through C++ shared_ptrs, which Python's GC cannot collect, so a grad-enabled forward that is never
+        # backpropagated (validation without no_grad, an exception before backward) leaked the whole workspace.  What the
+        # backward needs of them (the alignments) goes through save_for_backward, which autograd handles without a cycle.
+        mel, gate, align, align_sub = dp.mel, dp.gate, dp.align, dp.align_sub
+        dp.mel = dp.gate = dp.align = dp.align_sub = None
         ctx.cfg, ctx.dp, ctx.P, ctx.W = cfg, dp, P, W
-        ctx.save_for_backward(*((memory,) if memory_sub is None else (memory, memory_sub)))
+        ctx.out_meta = (mel.shape, gate.shape, mel.dtype, mel.device)
+        ctx.has_sub = memory_sub is not None
+        ctx.save_for_backward(*((memory, align, align_sub) if memory_sub is None else (memory, memory_sub, align, align_sub)))
         ctx.set_materialize_grads(False)
-        return dp.mel, dp.gate, dp.align, dp.align_sub
+        return mel, gate, align, align_sub
 
     @staticmethod
     def backward(ctx, d_mel, d_gate, d_align, d_align_sub):
         cfg, dp = ctx.cfg, ctx.dp
-        memory, memory_sub = (ctx.saved_tensors + (None,))[:2]
-        c = lambda g, ref: torch.zeros_like(ref) if g is None else g.contiguous()
+        saved = ctx.saved_tensors
+        memory, memory_sub = saved[0], (saved[1] if ctx.has_sub else None)
+        dp.align, dp.align_sub = saved[-2], saved[-1]
+        mel_shape, gate_shape, dt, dev = ctx.out_meta
+        c = lambda g, shape: torch.zeros(shape, dtype=dt, device=dev) if g is None else g.contiguous()
         cz = lambda g: None if g is None else g.contiguous()
         # Only d(memory) feeds further backward nodes (the encoders); the weight gradients are leaves.  With
         # defer_weight_grads the library leaves them on its side stream underneath the encoders' backward, and the
@@ -149,8 +160,8 @@ class _DecoderFn(torch.autograd.Function):
         # an accumulation into an existing .grad would read it on this stream too early)
         dec = cfg["decoder"]
         keep = [] if (getattr(dec, "defer_weight_grads", False) and all(p.grad is None for p in dec.parameters())) else None
-        G, dm, dms = ops.decoder_backward(ctx.W, ctx.P, cfg["decoder"].dims, dp, memory, memory_sub, c(d_mel, dp.mel),
-                                          c(d_gate, dp.gate), training=cfg["training"], prenet_dropout=cfg["prenet_dropout"],
+        G, dm, dms = ops.decoder_backward(ctx.W, ctx.P, cfg["decoder"].dims, dp, memory, memory_sub, c(d_mel, mel_shape),
+                                          c(d_gate, gate_shape), training=cfg["training"], prenet_dropout=cfg["prenet_dropout"],
                                           seed=cfg["seed"], d_align=cz(d_align), d_align_sub=cz(d_align_sub), defer=keep)
         if keep is not None:
             def _join(keep=keep):
@@ -189,9 +200,8 @@ class Decoder(nn.Module):
         att_cls = {"StepwiseMonotonicAttention": StepwiseMonotonicAttention, "ForwardAttentionV2": ForwardAttentionV2,
                    "GMMAttention": GMMAttention, "DynamicConvolutionAttention": DynamicConvolutionAttention,
                    "LSA": LocationSensitiveAttention, "LocationSensitiveAttention": LocationSensitiveAttention}.get(hp.attention)
-        if att_cls is None:
-            raise ValueError(f"unknown attention '{hp.attention}': StepwiseMonotonicAttention, LSA, ForwardAttentionV2, "
-                             "GMMAttention or DynamicConvolutionAttention")
+        if att_cls is None:                                               # model.py:182-191: anything else is LSA
+            att_cls = LocationSensitiveAttention
         print({"SMA": "Use SMA", "LSA": "Use LSA", "FWD2": "Use ForwardAttention", "GMM": "Use GMMA",
                "DCA": "Use DCA"}[att_cls.kind])                          # model.py:159-191
         args = (Ha, E, hp.attention_dim, hp.attention_location_n_filters, hp.attention_location_kernel_size)
@@ -203,12 +213,22 @@ class Decoder(nn.Module):
             self.decoder_rnn_bert = nn.LSTMCell(Ha + E, Hd, 1)  # dead in the reference too (model.py:197-199, :375-378)
         self.linear_projection = LinearNorm(Hd + ns * E, M)
         self.gate_layer = LinearNorm(Hd + ns * E, 1, bias=True, w_init_gain="sigmoid")
-        self.dims = L.dims_from_hparams(hp, ns)
+        self._dims = L.dims_from_hparams(hp, ns)
         self.prenet_dropout = True          # model.py:23 (always on); tests switch it off for deterministic parity
         self.defer_weight_grads = False     # True: weight gradients finish on the library's side stream (see _DecoderFn); measured: +0.5 %
         self.base_seed, self._calls = int(getattr(hp, "seed", 1234)), 0
 
     # -- helpers ---------------------------------------------------------------------------
+    @property
+    def dims(self):
+        """Model dimensions for the C ABI, with the attention modules' score_mask_value as it stands now: callers poke it
+        from outside (train.py:77-78 sets decoder.attention_layer.score_mask_value for fp16 runs)."""
+        d = self._dims
+        d.score_mask_value = float(self.attention_layer.score_mask_value)
+        if not self.single:
+            d.score_mask_value_sub = float(self.attention_layer_bert.score_mask_value)
+        return d
+
     def _param_keys(self):
         return L.decoder_param_keys(self.dims.attention_kind, self.single)
 

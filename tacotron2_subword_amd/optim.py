@@ -24,10 +24,24 @@ class _AdamTensor(C.Structure):
 class FusedAdam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, foreach=False)
-        self._host = None            # pinned staging of the tensor table
+        # Two pinned staging tables used alternately, each guarded by an event recorded behind its upload: the host may run
+        # a full iteration ahead of the GPU (no sync in the training loop), and p.grad addresses change every step, so a
+        # single table could be overwritten before its H2D copy had run.
+        self._slots = [dict(host=None, event=None), dict(host=None, event=None)]
+        self._turn = 0
         self._dev = None
         self._partial = None
         self.last_norm = None
+
+    def _table(self, nbytes):
+        """Next pinned table of at least nbytes; waits (host side) for the upload that last used it."""
+        slot = self._slots[self._turn]
+        self._turn ^= 1
+        if slot["event"] is not None:
+            slot["event"].synchronize()
+        if slot["host"] is None or slot["host"].numel() < nbytes:
+            slot["host"] = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        return slot
 
     @torch.no_grad()
     def step(self, closure=None, max_norm=None):
@@ -37,11 +51,11 @@ class FusedAdam(torch.optim.Adam):
                 loss = closure()
         lib = L.lib()
         lib.t2_adam_chunks.argtypes, lib.t2_adam_chunks.restype = [C.c_long], C.c_int
-        norm_out = None
-        for group in self.param_groups:
-            rows, chunk = [], 0
-            b1, b2 = group["betas"]
-            step = None
+        # One gradient norm over ALL parameter groups (clip_grad_norm_(model.parameters()), train.py:322-323).  Rows are
+        # grouped by (hyper-parameters, step count): torch.optim.Adam corrects the bias with each parameter's own step,
+        # which differs between parameters once one of them starts receiving gradients later or a state is partly restored.
+        batches = {}
+        for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -53,26 +67,45 @@ class FusedAdam(torch.optim.Adam):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
-                step = int(st["step"].item()) if step is None else step
+                batches.setdefault((gi, int(st["step"].item())), []).append(p)
+        if not batches:
+            self.last_norm = None
+            return loss if closure is not None else None
+        order = sorted(batches)
+        rows, spans, chunk = [], [], 0
+        for key in order:
+            first, chunk0 = len(rows), chunk
+            for p in batches[key]:
+                st = self.state[p]
                 rows.append((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), chunk))
                 chunk += lib.t2_adam_chunks(p.numel())
-            if not rows:
-                continue
-            n = len(rows)
-            if self._host is None or self._host.numel() < n * 48:
-                self._host = torch.empty(n * 48, dtype=torch.uint8).pin_memory()
-                self._dev = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
-            tab = (_AdamTensor * n).from_buffer(memoryview(self._host.numpy())[:n * 48])
-            for i, r in enumerate(rows):
-                tab[i].p, tab[i].g, tab[i].m, tab[i].v, tab[i].numel, tab[i].first_chunk = r
-            self._dev[:n * 48].copy_(self._host[:n * 48], non_blocking=True)
-            if self._partial is None or self._partial.numel() < chunk + 2:
-                self._partial = torch.empty(chunk + 2, dtype=torch.float32, device="cuda")
-            norm_out = torch.empty(2, dtype=torch.float32, device="cuda")
-            lib.t2_adam_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
-                                         C.c_float, C.c_float, C.c_int, C.c_void_p]
-            L.check(lib.t2_adam_step(self._dev.data_ptr(), n, chunk, self._partial.data_ptr(), norm_out.data_ptr(),
-                                     float(max_norm) if max_norm else 0.0, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                     float(group["weight_decay"]), step, L.stream()))
-        self.last_norm = None if norm_out is None else norm_out[0]
+            spans.append((first, len(rows) - first, chunk - chunk0))
+        n = len(rows)
+        slot = self._table(n * 48)
+        tab = (_AdamTensor * n).from_buffer(memoryview(slot["host"].numpy())[:n * 48])
+        for i, r in enumerate(rows):
+            tab[i].p, tab[i].g, tab[i].m, tab[i].v, tab[i].numel, tab[i].first_chunk = r
+        if self._dev is None or self._dev.numel() < n * 48:
+            self._dev = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+        self._dev[:n * 48].copy_(slot["host"][:n * 48], non_blocking=True)
+        slot["event"] = torch.cuda.Event()
+        slot["event"].record()
+        if self._partial is None or self._partial.numel() < chunk + 2:
+            self._partial = torch.empty(chunk + 2, dtype=torch.float32, device="cuda")
+        norm_out = torch.empty(2, dtype=torch.float32, device="cuda")
+        lib.t2_adam_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
+                                     C.c_float, C.c_float, C.c_int, C.c_void_p]
+        lib.t2_adam_norm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        single = len(order) == 1
+        if not single:       # norm + clip coefficient over every row first, then one update launch per (group, step)
+            L.check(lib.t2_adam_norm(self._dev.data_ptr(), n, chunk, self._partial.data_ptr(), norm_out.data_ptr(),
+                                     float(max_norm) if max_norm else 0.0, L.stream()))
+        for (gi, step), (first, cnt, nchunks) in zip(order, spans):
+            group = self.param_groups[gi]
+            b1, b2 = group["betas"]
+            # single batch: norm and update in one call; otherwise max_norm < 0 = "use the coefficient already in norm_out"
+            L.check(lib.t2_adam_step(self._dev.data_ptr() + first * 48, cnt, nchunks, self._partial.data_ptr(), norm_out.data_ptr(),
+                                     (float(max_norm) if max_norm else 0.0) if single else -1.0, float(group["lr"]), float(b1), float(b2),
+                                     float(group["eps"]), float(group["weight_decay"]), step, L.stream()))
+        self.last_norm = norm_out[0]
         return loss if closure is not None else self.last_norm

@@ -77,6 +77,84 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+class Late(nn.Module):
+    """`late` takes part in the loss only from the third step on: its first gradient arrives after the set of live
+    parameters has been snapshotted (a layer unfrozen mid-run)."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(6, 5)
+        self.late = nn.Linear(5, 5)
+        self.b = nn.Linear(5, 2)
+        self.use_late = False
+
+    def forward(self, x):
+        h = torch.tanh(self.a(x))
+        if self.use_late:
+            h = h + self.late(h)
+        return self.b(h)
+
+
+def _worker_late(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tacotron2_subword_amd import distributed as D
+        old = D._BUCKET_BYTES
+        for bucket_bytes in (old, 64):                   # one bucket for everything / one bucket per tensor
+            D._BUCKET_BYTES = bucket_bytes
+            D.GradArena.__init__.__defaults__ = (bucket_bytes,)
+            torch.manual_seed(5)
+            m = D.apply_gradient_allreduce(Late())
+            sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+            for step in range(5):
+                m.use_late = step >= 2
+                m.zero_grad()
+                g = torch.Generator().manual_seed(11 * step + rank)
+                m(torch.randn(4, 6, generator=g)).pow(2).sum().backward()
+                ref = Late()
+                ref.load_state_dict(sd0)
+                ref.use_late = m.use_late
+                loc = []
+                for r in range(world):
+                    ref.zero_grad()
+                    gr = torch.Generator().manual_seed(11 * step + r)
+                    ref(torch.randn(4, 6, generator=gr)).pow(2).sum().backward()
+                    loc.append({k: p.grad.clone() for k, p in ref.named_parameters() if p.grad is not None})
+                for k, p in m.named_parameters():
+                    if k.startswith("late") and step < 2:
+                        assert p.grad is None or float(p.grad.abs().max()) == 0.0, (bucket_bytes, step, k)
+                        continue
+                    want = sum(l[k] for l in loc) / world
+                    assert torch.allclose(p.grad, want, atol=1e-6), (bucket_bytes, step, k, (p.grad - want).abs().max())
+        q.put((rank, "ok", None))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, "fail", traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_world2(worker):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, info in out:
+        assert status == "ok", f"rank {rank}: {info}"
+
+
+def test_parameter_that_starts_receiving_gradients_later_is_averaged():
+    """A parameter whose first gradient arrives after step 1 (bucket readiness miscount): averaged over
+    ranks from its first step on, with one bucket for everything and with one bucket per tensor."""
+    _run_world2(_worker_late)
+
+
 def test_gradient_allreduce_world2_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

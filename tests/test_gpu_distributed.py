@@ -72,6 +72,70 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _worker_nccl(rank, world, port, q):
+    """world_size-1 process group over RCCL (backend "nccl" IS RCCL on ROCm): the bucketed, hook-launched
+    all_reduce(async_op=True) path of the wrapper on a real RCCL stream, in the bf16 mode bench.py runs, persistent
+    chain kernels and side streams included.  With one rank the averaged gradient must equal the local one."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    try:
+        from tacotron2_subword_amd import _lib as L
+        from tacotron2_subword_amd.hparams import create_hparams
+        from tacotron2_subword_amd.model import BERT_Tacotron2
+        from tacotron2_subword_amd.loss_function import Tacotron2Loss
+        from tacotron2_subword_amd.distributed import apply_gradient_allreduce
+        from tacotron2_subword_amd import train as T
+        reduce_tensor = T.reduce_tensor
+        L.set_precision("bf16")
+        hp = create_hparams()
+        B, Tin, Tsub, Tn = 8, 24, 15, 40
+        torch.manual_seed(1234)
+        ref = BERT_Tacotron2(hp).cuda().eval()
+        ref.decoder.prenet_dropout = False
+        m = BERT_Tacotron2(hp).cuda().eval()
+        m.decoder.prenet_dropout = False
+        m.load_state_dict(ref.state_dict())
+        m = apply_gradient_allreduce(m)
+
+        def grads(model, seed):
+            x, y = model.parse_batch(T.synthetic_batch(hp, B, Tin, Tsub, Tn, seed=seed))
+            model.zero_grad()
+            loss = Tacotron2Loss()(model(x), y, x)[0]
+            loss.backward()
+            torch.cuda.synchronize()
+            return float(loss), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+        for step in range(3):                              # step 0: reduction at the end of backward; later: from the hooks
+            l0, want = grads(ref, 70 + step)
+            l1, got = grads(m, 70 + step)
+            assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l0))
+            assert set(got) == set(want)
+            for k in want:
+                err = float((got[k] - want[k]).abs().max()) / max(float(want[k].abs().max()), 1e-6)
+                assert err < 1e-5, (step, k, err)
+        r = reduce_tensor(torch.tensor([3.0], device="cuda"), world)          # train.py:23-27
+        assert float(r) == 3.0
+        q.put((rank, "ok", ""))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, "fail", traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_world1_real_model_bf16():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_nccl, args=(0, 1, _free_port(), q))
+    p.start()
+    rank, status, info = q.get(timeout=600)
+    p.join(timeout=60)
+    assert status == "ok", info
+
+
 def test_dp_world2_real_model_on_gpu():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
