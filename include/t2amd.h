@@ -60,6 +60,10 @@ int t2_set_overlap(int on);
  * (t2_decoder_layout.chain); 0: one launch per step and kernel, as in round 1. */
 int t2_set_chain(int on);
 int t2_get_chain(void);
+/* The backward pass's persistent chains (csrc/chain_bwd.hip; in effect only while t2_set_chain is on): 1 (default; env
+ * T2_CHAIN_BWD=0 turns it off) runs the BPTT of the decoder LSTM (autograd of model.py:371-373) in one launch per step
+ * range, W_hh^T resident in registers.  t2_decoder_backward then writes status word 2 of the forward workspace's chain block. */
+int t2_set_chain_bwd(int on);
 /* bf16 mode only.  1 (default): a large GEMM whose extents are whole 128x128x64 tiles first writes bf16 copies of its
  * fp32 operands (K contiguous) into the caller's scratch and runs the bf16-source kernel on them (half the operand
  * bytes per MFMA; implicit-conv operands included).  0: always convert while staging through LDS.  Same rounding
@@ -188,6 +192,9 @@ typedef struct t2_decoder_bwd_layout {
     size_t ddout, ddin, dgd, dga, dgas, dctx, dctxs, dq, dqs, dv, dvs, dpm, dpms, carry, carrys;
     size_t carryc, carrycs, dlconv, dlconvs, dldense, dldenses;   /* LSA: cumulative carry, per-item location-layer gradients; GMM: mean carry, per-item db2 / dW2; zero-sized for SMA */
     size_t dcd, dca, dcas, partd, parta, dp2, dp2s, dp1, dmel_t, dgate_t, dg16a, dg16d, colsum_ws, gemm_ws, gemm_ws_floats;
+    size_t chain, chain_floats;   /* exchange buffers of the persistent backward chains (gate-gradient fragments, K-split partials,
+                                   * arrival counters); their status words are words 2 (decoder-LSTM chain) and 3 (attention chain)
+                                   * of the forward workspace's t2_decoder_layout.chain block */
 } t2_decoder_bwd_layout;
 int t2_decoder_bwd_layout_query(const t2_dims* dims, int B, int T, int Tin, int Tsub, t2_decoder_bwd_layout* out);
 typedef struct t2_decoder_bwd_args {

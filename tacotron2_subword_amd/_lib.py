@@ -90,7 +90,7 @@ class DecoderGrads(C.Structure):
 
 _BWD_LAYOUT_FIELDS = ["total_floats", "ddout", "ddin", "dgd", "dga", "dgas", "dctx", "dctxs", "dq", "dqs", "dv", "dvs",
                       "dpm", "dpms", "carry", "carrys", "carryc", "carrycs", "dlconv", "dlconvs", "dldense", "dldenses", "dcd", "dca", "dcas", "partd", "parta", "dp2", "dp2s", "dp1",
-                      "dmel_t", "dgate_t", "dg16a", "dg16d", "colsum_ws", "gemm_ws", "gemm_ws_floats"]
+                      "dmel_t", "dgate_t", "dg16a", "dg16d", "colsum_ws", "gemm_ws", "gemm_ws_floats", "chain", "chain_floats"]
 
 
 class DecoderBwdLayout(C.Structure):
@@ -150,7 +150,7 @@ class GemmArgs(C.Structure):
 
 
 # every symbol include/t2amd.h declares (tests/test_abi.py checks the library exports them all)
-EXPORTS = ["t2_last_error", "t2_version", "t2_set_precision", "t2_get_precision", "t2_set_overlap", "t2_set_chain", "t2_get_chain", "t2_set_gemm_staging", "t2_side_join", "t2_decoder_layout_query", "t2_decoder_forward", "t2_decoder_infer",
+EXPORTS = ["t2_last_error", "t2_version", "t2_set_precision", "t2_get_precision", "t2_set_overlap", "t2_set_chain", "t2_get_chain", "t2_set_chain_bwd", "t2_set_gemm_staging", "t2_side_join", "t2_decoder_layout_query", "t2_decoder_forward", "t2_decoder_infer",
            "t2_decoder_bwd_layout_query", "t2_decoder_backward", "t2_prof_enable", "t2_prof_collect", "t2_adam_chunks", "t2_adam_step", "t2_adam_norm",
            "t2_conv_bn_forward", "t2_conv_bn_backward", "t2_embedding_forward", "t2_embedding_backward",
            "t2_lstm_seq_forward", "t2_lstm_seq_backward", "t2_gemm_ex", "t2_colsum", "t2_mask_btc",
@@ -362,7 +362,7 @@ def decoder_layout(dims: Dims, B: int, T: int, Tin: int, Tsub: int) -> DecoderLa
 
 
 PROF_KINDS = ["att_lstm_fwd", "attention_fwd", "dec_lstm_fwd", "attention_bwd", "att_lstm_bwd_pointwise",
-              "att_lstm_bwd_gemm", "dec_lstm_bwd_pointwise", "dec_lstm_bwd_gemm", "chain_a_fwd", "chain_b_fwd"]
+              "att_lstm_bwd_gemm", "dec_lstm_bwd_pointwise", "dec_lstm_bwd_gemm", "chain_a_fwd", "chain_b_fwd", "chain_b_bwd", "chain_a_bwd"]
 
 
 def prof_enable(max_launches: int) -> None:
@@ -380,6 +380,10 @@ def prof_collect() -> dict:
 def set_chain(on: bool) -> None:
     """Persistent chain kernels for teacher-forced passes (include/t2amd.h: t2_set_chain)."""
     check(lib().t2_set_chain(int(bool(on))))
+
+
+def set_chain_bwd(on: bool) -> None:
+    check(lib().t2_set_chain_bwd(int(bool(on))))
 
 
 def get_chain() -> bool:

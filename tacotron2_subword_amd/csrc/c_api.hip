@@ -33,7 +33,7 @@ using namespace t2;
 // the per-step kernel launches with HIP events on the launch stream.  Off by default.
 // ---------------------------------------------------------------------------------------------
 enum ProfKind { PK_LSTM_ATT_FWD = 0, PK_ATTN_FWD, PK_LSTM_DEC_FWD, PK_ATTN_BWD, PK_LSTM_ATT_BWD_PW, PK_LSTM_ATT_BWD_GEMM,
-                PK_LSTM_DEC_BWD_PW, PK_LSTM_DEC_BWD_GEMM, PK_CHAIN_A_FWD, PK_CHAIN_B_FWD, PK_COUNT };
+                PK_LSTM_DEC_BWD_PW, PK_LSTM_DEC_BWD_GEMM, PK_CHAIN_A_FWD, PK_CHAIN_B_FWD, PK_CHAIN_B_BWD, PK_CHAIN_A_BWD, PK_COUNT };
 struct Prof {
     bool on = false;
     std::vector<hipEvent_t> ev;
@@ -63,6 +63,7 @@ struct Side { hipStream_t s = nullptr; std::vector<hipEvent_t> ev; };
 static Side g_side[16];
 static int g_overlap = 1;
 static int g_chain = getenv("T2_CHAIN") ? atoi(getenv("T2_CHAIN")) : 1;   // persistent chain kernels (chain.hip)
+static int g_chain_bwd = getenv("T2_CHAIN_BWD") ? atoi(getenv("T2_CHAIN_BWD")) : 1;   // ... of the backward pass (chain_bwd.hip)
 static int side_get(Side** out) {
     int dev = 0;
     T2_CHECK_HIP(hipGetDevice(&dev));
@@ -569,6 +570,13 @@ void bwd_layout_of(const t2_dims& d, const Sizes& z, t2_decoder_bwd_layout* L) {
     L->colsum_ws = take((size_t)64 * 4 * (z.Ha > z.Hd ? z.Ha : z.Hd));
     L->gemm_ws_floats = (size_t)128 << 20;                    // 512 MiB: split-K partials + bf16 operand staging (gemm.hip)
     L->gemm_ws = take(L->gemm_ws_floats);
+    {   // persistent backward chains (chain_bwd.hip): counters | dg fragments | K-split partials of the decoder-LSTM chain
+        ChainBwdDesc cd{}; cd.kind = CHAIN_LSTM; cd.B = z.B; cd.H = z.Hd;
+        size_t xb = 0, pb = 0;
+        chain_bwd_exchange_bytes(cd, &xb, &pb);
+        L->chain_floats = (kChainBwdCntBytes + xb + pb + 255) / sizeof(float);
+        L->chain = take(L->chain_floats);
+    }
     L->total_floats = off;
 }
 
@@ -632,6 +640,32 @@ int dec_bwd_step(const Bwd& c, int t) {
     if (c.use16) { g.st[0].dg16 = c.S16(c.BL.dg16d); g.st[0].wt16 = c.W16(c.L.wt16d); }
     ProfScope ps(PK_LSTM_DEC_BWD_GEMM, sd);
     return lstm_bwd_gemm(g, sd);
+}
+
+// Persistent BPTT of the decoder LSTM (chain_bwd.hip); false = not covered, per-step launches instead
+bool chain_b_bwd_desc(const Bwd& c, ChainBwdDesc* out) {
+    const Sizes& z = c.z;
+    if (!c.use16) return false;
+    ChainBwdDesc d{};
+    d.NS = 1; d.B = z.B; d.T = z.T; d.H = z.Hd; d.kind = CHAIN_LSTM;
+    d.drop_p = c.a.training ? c.d.p_dec_dropout : 0.f; d.seed = c.a.seed;
+    ChainBwdStream& st = d.st[0];
+    st.wt16 = c.W16(c.L.wt16d); st.ldwt = 4 * z.Hd;
+    st.dh1 = c.S(c.BL.ddout); st.lddh1 = z.WO;
+    st.gates = c.W(c.L.gd); st.c_new = c.W(c.L.cnd); st.c_out = c.W(c.L.cd);
+    st.dg = c.S(c.BL.dgd); st.dc_state = c.S(c.BL.dcd);
+    st.site_h = T2_SITE_DEC_H; st.site_c = T2_SITE_DEC_C;
+    if (!chain_bwd_plan(d)) return false;
+    size_t xb = 0, pb = 0;
+    chain_bwd_exchange_bytes(d, &xb, &pb);
+    if ((kChainBwdCntBytes + xb + pb + 3) / 4 > c.BL.chain_floats) return false;
+    unsigned char* p = reinterpret_cast<unsigned char*>(c.S(c.BL.chain));
+    d.cnt = reinterpret_cast<unsigned*>(p); p += kChainBwdCntBytes;
+    d.X = p; p += xb;
+    d.PB = p; d.pb_bytes = (unsigned)pb;
+    d.err = reinterpret_cast<unsigned*>(const_cast<float*>(c.a.ws) + c.L.chain) + 2;      // status word 2 of the forward block
+    *out = d;
+    return true;
 }
 
 int att_bwd_step(const Bwd& c, int t) {
@@ -767,6 +801,7 @@ int t2_get_precision(void) { return get_precision(); }
 int t2_set_overlap(int on) { g_overlap = on != 0; return 0; }
 int t2_set_chain(int on) { g_chain = on != 0; return 0; }
 int t2_get_chain(void) { return g_chain; }
+int t2_set_chain_bwd(int on) { g_chain_bwd = on != 0; return 0; }
 int t2_set_gemm_staging(int on) { set_gemm_staging(on); return 0; }
 int t2_side_join(void* stream) {
     Side* side = nullptr;
@@ -950,10 +985,18 @@ int t2_decoder_backward(const t2_dims* dims_in, const t2_decoder_weights* w, con
     const size_t wt_bytes = ((size_t)4 * z.Hd * z.WD * sizeof(__bf16) + 255) & ~(size_t)255;
     const bool pre16 = get_precision() == 1 && (4 * z.Hd) % 64 == 0 && z.WD % 64 == 0 && c.gemm_ws_bytes() > 2 * wt_bytes;
     if (pre16) T2_TRY(stage_bf16(w->dec.w_ih, false, z.WD, reinterpret_cast<__bf16*>(ws8), z.WD, 4 * z.Hd, overlap ? side->s : c.s));
+    ChainBwdDesc cbb{};
+    const bool chain_b = g_chain && g_chain_bwd && chain_b_bwd_desc(c, &cbb);
     for (size_t ci = bounds.size() - 1; ci > 0; --ci) {
         const int t0 = bounds[ci - 1], t1 = bounds[ci];
         hipStream_t sb = overlap ? side->s : c.s;
-        for (int t = t1 - 1; t >= t0; --t) T2_TRY(dec_bwd_step(c, t));
+        if (chain_b) {
+            cbb.t0 = t0; cbb.t1 = t1;
+            ProfScope ps(PK_CHAIN_B_BWD, sb);
+            T2_TRY(chain_bwd(cbb, sb));
+        } else {
+            for (int t = t1 - 1; t >= t0; --t) T2_TRY(dec_bwd_step(c, t));
+        }
         GemmDesc dd = matmul_nn(DGd + c.R(t0) * 4 * z.Hd, 4 * z.Hd, w->dec.w_ih, z.WD, c.S(BL.ddin) + c.R(t0) * z.WD, z.WD,
                                 (t1 - t0) * z.B, z.WD, 4 * z.Hd);
         dd.ws = c.gemm_ws(); dd.ws_bytes = c.gemm_ws_bytes();             // between fork and join the scratch is chain B's

@@ -219,6 +219,25 @@ constexpr size_t kChainCntBytes = 2 * 4 * 2 * 128; // arrival counters: [NS][row
 int chain_fwd(const ChainDesc& d, hipStream_t s);
 int chain_device_cus();
 
+// Backward (BPTT) of a chain in one launch (chain_bwd.hip)
+struct ChainBwdStream {
+    const __bf16* wt16; long ldwt;        // [N][4H] transposed bf16 shadow of the recurrent weights, K (= gate columns) contiguous
+    const float* dh1; long lddh1;         // direct gradient on h_out(t): dh1[(t*B + b)*lddh1 + u]
+    const float* gates; const float* c_new; const float* c_out;   // saved by the forward pass: [T][B][4H], [T][B][H] x2
+    float* dg;                            // out: gate pre-activation gradients [T][B][4H]
+    float* dc_state;                      // [B][H] dL/dc carried between launches of one pass (chunked ranges)
+    uint32_t site_h, site_c;
+};
+struct ChainBwdDesc {
+    ChainBwdStream st[2]; int NS, B, T, t0, t1, H, kind;
+    float drop_p; uint64_t seed;
+    unsigned char* X; unsigned char* PB; unsigned* cnt; unsigned* err; unsigned pb_bytes;   // exchange: dg fragments, K-split partials
+};
+constexpr size_t kChainBwdCntBytes = 64 * 128;     // arrival counters, one per 128-byte line
+bool chain_bwd_plan(ChainBwdDesc& d);
+size_t chain_bwd_exchange_bytes(const ChainBwdDesc& d, size_t* x_bytes, size_t* pb_bytes);
+int chain_bwd(const ChainBwdDesc& d, hipStream_t s);
+
 // ------------------------------------------------------------------ decode-step tail (infer.hip)
 // projection + stop rule of step t and both prenets of step t+1, one workgroup per batch item
 struct StepTailDesc {

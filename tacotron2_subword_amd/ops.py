@@ -55,10 +55,11 @@ class DecoderPass:
         self.align_sub = torch.empty(B, T, Tsub, dtype=torch.float32, device=device)
 
     def chain_status(self):
-        """(attention chain, decoder-LSTM chain) status words of the persistent kernels: 0 = completed (or not used).
+        """Status words of the persistent kernels — (forward attention chain, forward decoder-LSTM chain, backward
+        decoder-LSTM chain, backward attention chain): 0 = completed (or not used).
         Synchronises the device: for tests and the end of a benchmark, not for the training loop."""
-        w = self.ws[self.layout.chain:self.layout.chain + 2].view(torch.int32).cpu()
-        return int(w[0]), int(w[1])
+        w = self.ws[self.layout.chain:self.layout.chain + 4].view(torch.int32).cpu()
+        return tuple(int(v) for v in w)
 
     def view(self, name: str, *shape) -> torch.Tensor:
         off = getattr(self.layout, name)
