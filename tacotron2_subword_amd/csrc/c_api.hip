@@ -570,11 +570,15 @@ void bwd_layout_of(const t2_dims& d, const Sizes& z, t2_decoder_bwd_layout* L) {
     L->colsum_ws = take((size_t)64 * 4 * (z.Ha > z.Hd ? z.Ha : z.Hd));
     L->gemm_ws_floats = (size_t)128 << 20;                    // 512 MiB: split-K partials + bf16 operand staging (gemm.hip)
     L->gemm_ws = take(L->gemm_ws_floats);
-    {   // persistent backward chains (chain_bwd.hip): counters | dg fragments | K-split partials of the decoder-LSTM chain
+    {   // persistent backward chains (chain_bwd.hip): [counters | dg fragments | K-split partials] of the decoder-LSTM chain,
+        // then [counters | dg fragments | h partials | ctx partials | dq partials | boundary carries] of the attention chain
         ChainBwdDesc cd{}; cd.kind = CHAIN_LSTM; cd.B = z.B; cd.H = z.Hd;
         size_t xb = 0, pb = 0;
         chain_bwd_exchange_bytes(cd, &xb, &pb);
-        L->chain_floats = (kChainBwdCntBytes + xb + pb + 255) / sizeof(float);
+        ChainBwdDesc ca{}; ca.kind = CHAIN_SMA; ca.B = z.B; ca.H = z.Ha; ca.E = z.E; ca.A = z.A; ca.NS = z.NS;
+        size_t x2, ph, pc, dq, cr;
+        const size_t att = chain_bwd_att_exchange_bytes(ca, &x2, &ph, &pc, &dq, &cr);
+        L->chain_floats = (2 * kChainBwdCntBytes + xb + pb + att + 255) / sizeof(float);
         L->chain = take(L->chain_floats);
     }
     L->total_floats = off;
@@ -658,12 +662,57 @@ bool chain_b_bwd_desc(const Bwd& c, ChainBwdDesc* out) {
     if (!chain_bwd_plan(d)) return false;
     size_t xb = 0, pb = 0;
     chain_bwd_exchange_bytes(d, &xb, &pb);
-    if ((kChainBwdCntBytes + xb + pb + 3) / 4 > c.BL.chain_floats) return false;
+    if ((2 * kChainBwdCntBytes + xb + pb + 3) / 4 > c.BL.chain_floats) return false;
     unsigned char* p = reinterpret_cast<unsigned char*>(c.S(c.BL.chain));
     d.cnt = reinterpret_cast<unsigned*>(p); p += kChainBwdCntBytes;
     d.X = p; p += xb;
     d.PB = p; d.pb_bytes = (unsigned)pb;
     d.err = reinterpret_cast<unsigned*>(const_cast<float*>(c.a.ws) + c.L.chain) + 2;      // status word 2 of the forward block
+    *out = d;
+    return true;
+}
+
+// Persistent BPTT of the attention chain (both attention LSTMs + SMA attention); false = not covered
+bool chain_a_bwd_desc(const Bwd& c, ChainBwdDesc* out) {
+    const Sizes& z = c.z;
+    if (!c.use16 || c.d.attention_kind != T2_ATTN_SMA || attn_bwd_nsplit(c.d, z) != 2) return false;
+    ChainBwdDesc d{};
+    d.NS = z.NS; d.B = z.B; d.T = z.T; d.H = z.Ha; d.E = z.E; d.A = z.A; d.kind = CHAIN_SMA;
+    d.drop_p = c.a.training ? c.d.p_att_dropout : 0.f; d.seed = c.a.seed;
+    for (int s = 0; s < z.NS; ++s) {
+        ChainBwdStream& st = d.st[s];
+        const t2_attention_weights& aw = s ? c.w.attn_sub : c.w.attn;
+        const int hoff = s ? z.Ha + z.E : 0, coff = hoff + z.Ha;
+        st.wt16 = c.W16(s ? c.L.wt16as : c.L.wt16a); st.ldwt = 4 * z.Ha;
+        st.dh1 = c.S(c.BL.ddin) + hoff; st.lddh1 = z.WD;
+        st.gates = c.W(s ? c.L.gas : c.L.ga); st.c_new = c.W(s ? c.L.cnas : c.L.cna); st.c_out = c.W(s ? c.L.cas : c.L.ca);
+        st.dg = c.S(s ? c.BL.dgas : c.BL.dga); st.dc_state = c.S(s ? c.BL.dcas : c.BL.dca);
+        st.site_h = s ? T2_SITE_ATT_H_SUB : T2_SITE_ATT_H; st.site_c = s ? T2_SITE_ATT_C_SUB : T2_SITE_ATT_C;
+        st.dctx_a = c.S(c.BL.ddout) + z.Hd + (s ? z.E : 0); st.lddctx_a = z.WO;
+        st.dctx_b = c.S(c.BL.ddin) + coff; st.lddctx_b = z.WD;
+        st.dalign = s ? c.a.d_align_sub : c.a.d_align;
+        st.qs = c.W(s ? c.L.qss : c.L.qs); st.pm = c.W(s ? c.L.pms : c.L.pm); st.memory = s ? c.a.memory_sub : c.a.memory;
+        st.Tin = s ? z.Tsub : z.Tin;
+        st.psel = c.W(s ? c.L.psels : c.L.psel); st.align = s ? c.a.align_sub : c.a.align;
+        st.v = aw.v; st.wq = aw.wq;
+        st.dctx_out = c.S(s ? c.BL.dctxs : c.BL.dctx); st.dq_out = c.S(s ? c.BL.dqs : c.BL.dq);
+        st.dv_acc = c.S(s ? c.BL.dvs : c.BL.dv); st.dpm_acc = c.S(s ? c.BL.dpms : c.BL.dpm);
+    }
+    if (!chain_bwd_plan(d)) return false;
+    ChainBwdDesc cd{}; cd.kind = CHAIN_LSTM; cd.B = z.B; cd.H = z.Hd;
+    size_t xb0 = 0, pb0 = 0;
+    chain_bwd_exchange_bytes(cd, &xb0, &pb0);
+    size_t xb, ph, pc, dq, cr;
+    const size_t att = chain_bwd_att_exchange_bytes(d, &xb, &ph, &pc, &dq, &cr);
+    if ((2 * kChainBwdCntBytes + xb0 + pb0 + att + 3) / 4 > c.BL.chain_floats) return false;
+    unsigned char* p = reinterpret_cast<unsigned char*>(c.S(c.BL.chain)) + kChainBwdCntBytes + xb0 + pb0;
+    d.cnt = reinterpret_cast<unsigned*>(p); p += kChainBwdCntBytes;
+    d.X = p; p += xb;
+    d.PB = p; p += ph; d.pb_bytes = (unsigned)ph;
+    d.PBC = p; p += pc; d.pbc_bytes = (unsigned)(2 * (size_t)z.NS * 4 * z.B * z.E * sizeof(float));
+    d.DQX = reinterpret_cast<float*>(p); p += dq;
+    d.CARRYX = reinterpret_cast<float*>(p);
+    d.err = reinterpret_cast<unsigned*>(const_cast<float*>(c.a.ws) + c.L.chain) + 3;      // status word 3 of the forward block
     *out = d;
     return true;
 }
@@ -971,8 +1020,12 @@ int t2_decoder_backward(const t2_dims* dims_in, const t2_decoder_weights* w, con
     // ---- two reverse-time chains, overlapped in chunks of steps (see Side above):
     //   B (side stream):     decoder-LSTM BPTT of a chunk, then dDIN rows of the chunk = dG . W_ih
     //   A (caller's stream): attention-LSTM + attention BPTT of the chunk B finished
+    // Persistent chains (chain_bwd.hip): a persistent grid needs the whole device, and two of them must never be in flight
+    // together, so with the attention chain persistent everything runs on the caller's stream, one step range per chain.
+    ChainBwdDesc cab{};
+    const bool chain_a = g_chain && g_chain_bwd && chain_a_bwd_desc(c, &cab);
     Side* side = nullptr;
-    const bool overlap = g_overlap && z.T >= 32;
+    const bool overlap = g_overlap && z.T >= 32 && !chain_a;
     size_t ne = 0;
     if (overlap) {
         T2_TRY(side_get(&side)); c.sd = side->s;
@@ -1030,7 +1083,13 @@ int t2_decoder_backward(const t2_dims* dims_in, const t2_decoder_weights* w, con
             else T2_TRY(fill_f32(g->dec.w_hh, 0.f, (size_t)4 * z.Hd * z.Hd, sb));
             T2_TRY(colsum(DG, 4 * z.Hd, BT, 4 * z.Hd, g->dec.b_ih, g->dec.b_hh, cws, sb));
         }
-        for (int t = t1 - 1; t >= t0; --t) T2_TRY(att_bwd_step(c, t));
+        if (chain_a) {
+            cab.t0 = t0; cab.t1 = t1;
+            ProfScope ps(PK_CHAIN_A_BWD, c.s);
+            T2_TRY(chain_bwd(cab, c.s));
+        } else {
+            for (int t = t1 - 1; t >= t0; --t) T2_TRY(att_bwd_step(c, t));
+        }
     }
     // ---- after the chains.  Only d(memory) feeds the caller's next backward nodes (the encoders); every weight gradient
     // is a leaf.  defer_weight_grads: the weight-gradient tail (and the decoder-LSTM weight gradients already queued

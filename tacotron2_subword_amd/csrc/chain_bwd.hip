@@ -192,12 +192,411 @@ __global__ __launch_bounds__(NTH) void chain_bwd_lstm_kernel(ChainBwdDesc d) {
     if (hasP && d.t0 > 0 && pb < B) S.dc_state[(long)pb * H + pu] = dc;       // for the launch that continues at t0 - 1
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Attention chain (autograd of model.py:322-369 with StepwiseMonotonicAttention, attention.py:291-398), reverse time.
+// Three phases per step, each workgroup holding one item of each kind:
+//   A item (b, s, split): half of the memory positions of one batch item and stream — attention.hip's
+//       attention_step_bwd_kernel with its operands resident: the item's processed-memory rows (fp32), its encoder-memory
+//       rows (bf16) and the d(processed memory) / dv accumulators stay in LDS for all steps, the carry of the recurrence
+//       too; only the boundary carry crosses to the other split (one float per step, write-through).
+//       total ctx gradient = two direct sources + 4 K-split partials of dx_ctx(t+1); g_j = dctx . memory_j (+ carry);
+//       recurrence and energies backward; dq partial -> P items.
+//   P item (s, ug, rt): 16 units x 32 rows of an attention LSTM: dh = direct + 4 K-split partials of dx_h(t+1) + dq . Wq
+//       (Wq slice resident in LDS), gate derivatives, dL/dc in a register, dg(t) published as bf16 fragments.
+//   G item (s, nt, kp): dx(t) = dg(t) . [W_ih[:,P:] | W_hh]: 64 of the 1536 output columns x one gate block (K = 1024) of
+//       the transposed shadow resident in registers (64 VGPRs); the 8 waves split K, partial tiles summed through LDS.
+// Hops per step: G(t+1) -> A(t) -> P(t) -> G(t).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int ANC = 64;          // output columns of a G item (attention chain)
+constexpr int AKP = 4;           // K parts = the four gate blocks
+
+struct BwdLds { int ab, v, q, dctx, g, de, ps, ap, carry, dva, dqo, wq, pm, dpm, mem, scratch, total; };
+__host__ __device__ inline BwdLds bwd_lds_of(int A, int E, int Tc, int MT) {
+    BwdLds m; int o = 0;
+    auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+    m.ab = take(4); m.v = take(A); m.q = take(A); m.dctx = take(E);
+    m.g = take(Tc + 8); m.de = take(Tc + 8); m.ps = take(Tc + 8); m.ap = take(Tc + 8); m.carry = take(Tc + 8);
+    m.dva = take(A); m.dqo = take(A);
+    m.wq = take(A * (PU + 1));
+    m.pm = take(Tc * A); m.dpm = take(Tc * A); m.mem = take((Tc + 1) * E / 2);
+    const int sg = NWV * 32 * PPR, sp = 32 * (A + 4) + 4 * 32 * (PU + 4), sa = 2 * 32 * A;
+    m.scratch = take(sg > sp ? (sg > sa ? sg : sa) : (sp > sa ? sp : sa));
+    m.total = o;
+    return m;
+}
+
+template <int MT>
+__global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
+    const int wg = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hk = lane >> 5;
+    const int B = d.B, H = d.H, K4 = 4 * H, E = d.E, A = d.A, N = E + H;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    // ---------------------------------------------------------------- items
+    const int NTT = N / ANC, NTC = E / ANC;                   // column tiles per stream (24), of which context tiles (8)
+    const int nGs = NTT * AKP, nPs = (H / PU) * MT, nAs = B * 2;
+    const bool hasG = wg < d.NS * nGs, hasP = wg < d.NS * nPs, hasA = wg < d.NS * nAs;
+    const int gs = hasG ? wg / nGs : 0, nt = (wg % nGs) % NTT, kp = (wg % nGs) / NTT;
+    const int ps = hasP ? wg / nPs : 0, ug = (wg % nPs) / MT, rt = (wg % nPs) % MT, u0 = ug * PU;
+    const int as = hasA ? wg / nAs : 0, ab_ = (wg % nAs) / 2, split = wg % 2;
+    const ChainBwdStream& GS = d.st[gs];
+    const ChainBwdStream& PS = d.st[ps];
+    const ChainBwdStream& AS = d.st[as];
+    const int Tin = AS.Tin;
+    const int chunk = (((Tin + 1) / 2) + 3) & ~3;
+    const int jb = min(split * chunk, Tin), je = min(jb + chunk, Tin), len = je - jb;
+    const int ng = je < Tin ? len + 1 : len;                   // g values computed here: positions [jb, jb + ng)
+    const BwdLds M = bwd_lds_of(A, E, d.lds_Tc, MT);
+    unsigned* abortw = reinterpret_cast<unsigned*>(smem + M.ab);
+    float* vL = smem + M.v; float* qL = smem + M.q; float* dctxL = smem + M.dctx; float* gL = smem + M.g; float* deL = smem + M.de;
+    float* psL = smem + M.ps; float* apL = smem + M.ap; float* carryL = smem + M.carry; float* dvaL = smem + M.dva; float* dqoL = smem + M.dqo;
+    float* wqL = smem + M.wq; float* pmL = smem + M.pm; float* dpmL = smem + M.dpm;
+    __bf16* memL = reinterpret_cast<__bf16*>(smem + M.mem);
+    float* partL = smem + M.scratch;                           // G: [NWV][32][PPR]
+    float* dqL = smem + M.scratch;                             // P: [32][A+4]
+    float* dgL = smem + M.scratch + 32 * (A + 4);              // P: [4][32][PU+4]
+    float* redL = smem + M.scratch;                            // A: [2][32][A]
+
+    const int KT = K4 / 16;
+    const unsigned xs = (unsigned)(KT * MT * 1024);            // dg fragments of one stream
+    auto rsX = __builtin_amdgcn_make_buffer_rsrc(d.X, 0, (int)(2u * d.NS * xs), 0x00020000);
+    auto rsH = __builtin_amdgcn_make_buffer_rsrc(d.PB, 0, (int)d.pb_bytes, 0x00020000);
+    auto rsC = __builtin_amdgcn_make_buffer_rsrc(d.PBC, 0, (int)d.pbc_bytes, 0x00020000);
+    auto rsQ = __builtin_amdgcn_make_buffer_rsrc(d.DQX, 0, d.NS * 2 * B * A * 4, 0x00020000);
+    auto rsK = __builtin_amdgcn_make_buffer_rsrc(d.CARRYX, 0, 2 * d.NS * B * 4, 0x00020000);
+    const unsigned pbh_half = d.pb_bytes / 2, pbc_half = d.pbc_bytes / 2;
+    const unsigned pbh_kp = (unsigned)((H / PU) * MT * 32 * PU * 4), pbh_s = pbh_kp * AKP;     // bytes per K part / per stream
+    const unsigned pbc_kp = (unsigned)(B * E * 4), pbc_s = pbc_kp * AKP;
+    // counters: [0..1] P done per stream, [2..3] ctx tiles done per stream, [4 + s*2 + rt] A done per (stream, row tile),
+    // [8 + s*16 + n] h tile n done
+    auto CNT = [&](int i) { return d.cnt + (size_t)i * CNT_STRIDE; };
+
+    if (tid == 0) *abortw = 0;
+
+    // ---------------------------------------------------------------- G setup: W^T slice -> registers
+    // wave w covers k in [kp*1024 + w*128, +128) (8 k-steps); column tile c of the item: columns nt*64 + c*32 + r
+    bf16x8 W[2][8];
+    if (hasG) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                W[c][i] = *reinterpret_cast<const bf16x8*>(GS.wt16 + (long)(nt * ANC + c * 32 + r) * GS.ldwt + kp * H + (wave * 8 + i) * 16 + 8 * hk);
+    }
+    // ---------------------------------------------------------------- P setup
+    const int pb = rt * 32 + (tid >> 4), pu = u0 + (tid & 15);
+    float dc = 0.f;
+    float pin[7];
+    auto load_pin = [&](int t, int tid) {
+        const int b = min(rt * 32 + (tid >> 4), B - 1), u = u0 + (tid & 15);
+        const long rb = (long)t * B + b;
+        pin[0] = PS.dh1[rb * PS.lddh1 + u];
+        const float* gp = PS.gates + rb * K4 + u;
+        pin[1] = gp[0]; pin[2] = gp[H]; pin[3] = gp[2 * H]; pin[4] = gp[3 * H];
+        pin[5] = PS.c_new[rb * H + u];
+        pin[6] = t > 0 ? PS.c_out[((long)(t - 1) * B + b) * H + u] : 0.f;
+    };
+    if (hasP) {
+        for (int i = tid; i < A * PU; i += NTH) wqL[(i / PU) * (PU + 1) + i % PU] = PS.wq[(long)(i / PU) * H + u0 + i % PU];
+        load_pin(d.t1 - 1, tid);
+    }
+    // ---------------------------------------------------------------- A setup: resident rows, zeroed accumulators
+    float ain[6];                                                   // per thread: q_a | p_j, a_prev_j, dalign_j | two direct dctx sources
+    auto load_ain = [&](int t, int tid) {
+        const long rb = (long)t * B + ab_;
+        ain[0] = tid < A ? AS.qs[rb * A + tid] : 0.f;
+        const int j = jb + tid;
+        const bool in = tid < ng;
+        ain[1] = (in && tid < len) ? AS.psel[((long)ab_ * d.T + t) * Tin + j] : 0.f;
+        ain[2] = (in && tid < len) ? (t > 0 ? AS.align[((long)ab_ * d.T + t - 1) * Tin + j] : (j == 0 ? 1.f : 0.f)) : 0.f;
+        ain[3] = (in && AS.dalign) ? AS.dalign[((long)ab_ * d.T + t) * Tin + j] : 0.f;
+        ain[4] = tid < E ? AS.dctx_a[rb * AS.lddctx_a + tid] : 0.f;
+        ain[5] = tid < E ? AS.dctx_b[rb * AS.lddctx_b + tid] : 0.f;
+    };
+    if (hasA) {
+        for (int a = tid; a < A; a += NTH) { vL[a] = AS.v[a]; dvaL[a] = 0.f; }
+        for (int i = tid; i < len * (A / 4); i += NTH) {
+            const int jl = i / (A / 4), a4 = (i % (A / 4)) * 4;
+            *reinterpret_cast<f32x4*>(pmL + jl * A + a4) = *reinterpret_cast<const f32x4*>(AS.pm + ((long)ab_ * Tin + jb + jl) * A + a4);
+            *reinterpret_cast<f32x4*>(dpmL + jl * A + a4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int i = tid; i < ng * (E / 4); i += NTH) {
+            const int jl = i / (E / 4), c4 = (i % (E / 4)) * 4;
+            const f32x4 m4 = *reinterpret_cast<const f32x4*>(AS.memory + ((long)ab_ * Tin + jb + jl) * E + c4);
+            bf16x4 o; o[0] = (__bf16)m4[0]; o[1] = (__bf16)m4[1]; o[2] = (__bf16)m4[2]; o[3] = (__bf16)m4[3];
+            *reinterpret_cast<bf16x4*>(memL + jl * E + c4) = o;
+        }
+        for (int j = tid; j < chunk + 8; j += NTH) carryL[j] = 0.f;
+        load_ain(d.t1 - 1, tid);
+    }
+    __syncthreads();
+    const RngKey kh = rng_key(d.seed, PS.site_h), kc = rng_key(d.seed, PS.site_c);
+    const float dscale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
+
+    for (int t = d.t1 - 1; t >= d.t0; --t) {
+        const unsigned ep = (unsigned)(d.t1 - 1 - t);
+        int tv = threadIdx.x;
+        asm volatile("" : "+v"(tv));
+        // ======================================================================================= A(t)
+        if (hasA) {
+            const int tid = tv, lane = tid & 63, wave = tid >> 6;
+            float in[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) in[i] = ain[i];
+            if (ep > 0) {
+                if (wave == 0 && !poll_counter(CNT(2 + as), ep * (unsigned)(NTC * AKP), d.err, 7u) && lane == 0) *abortw = 1;
+                __syncthreads();
+                if (*abortw) return;
+            }
+            // total gradient on ctx(t): direct sources + the four K-split partials of dx_ctx(t+1)
+            float boundary = 0.f;                                       // carry of position je, owned by the other split
+            if (tid < E) {
+                float v = in[4] + in[5];
+                if (ep > 0) {
+                    const unsigned off = (unsigned)((t + 1) & 1) * pbc_half + (unsigned)as * pbc_s + (unsigned)((ab_ * E + tid) * 4);
+                    float pv[AKP];
+#pragma unroll
+                    for (int z = 0; z < AKP; ++z) pv[z] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsC, off + z * pbc_kp, 0, SC1));
+                    v += (pv[0] + pv[1]) + (pv[2] + pv[3]);
+                }
+                dctxL[tid] = v;
+                if (split == 0) AS.dctx_out[((long)t * B + ab_) * E + tid] = v;
+            }
+            if (tid == 0 && ep > 0 && je < Tin)
+                boundary = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsK, (unsigned)((((t + 1) & 1) * d.NS + as) * B + ab_) * 4u, 0, SC1));
+            if (tid < A) qL[tid] = in[0];
+            if (tid < len) { psL[tid] = in[1]; apL[tid] = in[2]; }
+            if (tid == 0) { gL[ng] = 0.f; if (je < Tin) carryL[len] = boundary; }
+            __syncthreads();
+            // g_j = dctx . memory_j + dalign_j + carry_j: one wave per position, lanes stride the E columns 8 at a time
+            for (int jl = wave; jl < ng; jl += NWV) {
+                float sum = 0.f;
+                for (int c = lane * 8; c < E; c += 512) {
+                    const bf16x8 mb = *reinterpret_cast<const bf16x8*>(memL + jl * E + c);
+                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(dctxL + c), d1 = *reinterpret_cast<const f32x4*>(dctxL + c + 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sum += (float)mb[k] * d0[k] + (float)mb[4 + k] * d1[k];
+                }
+                sum = wave_sum(sum);
+                if (lane == 0) {
+                    float gsum = sum;
+                    gL[jl] = gsum;                                      // (+ dalign / carry added by the owning thread below)
+                }
+            }
+            __syncthreads();
+            if (tid < ng) {
+                float gsum = gL[tid] + in[3];
+                if (ep > 0) gsum += carryL[tid];
+                gL[tid] = gsum;
+            }
+            __syncthreads();
+            if (tid < len) {
+                const float p = psL[tid], gj = gL[tid], gn = gL[tid + 1];
+                deL[tid] = apL[tid] * (gj - gn) * p * (1.0f - p);
+                const float co = gj * p + gn * (1.0f - p);
+                carryL[tid] = co;                                       // gradient on a_{t-1}[j], consumed at step t-1
+                if (tid == 0 && split == 1)                             // position jb of this split = je of the other one
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, co), rsK, (unsigned)(((t & 1) * d.NS + as) * B + ab_) * 4u, 0, SC1);
+            }
+            __syncthreads();
+            // energies backward: 16 lanes per position, each lane owns channels sub*4 + 64*k
+            {
+                const int gid = tid >> 4, sub = tid & 15;
+                f32x4 dq[2], dv[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { dq[k] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                for (int jl = gid; jl < len; jl += NTH / 16) {
+                    const float dej = deL[jl];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int a = sub * 4 + 64 * k;
+                        const f32x4 pv = *reinterpret_cast<const f32x4*>(pmL + jl * A + a);
+                        f32x4 acc = *reinterpret_cast<const f32x4*>(dpmL + jl * A + a);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float u = fast_tanh(qL[a + c] + pv[c]);
+                            const float dpre = dej * vL[a + c] * (1.0f - u * u);
+                            dq[k][c] += dpre; dv[k][c] += dej * u; acc[c] += dpre;
+                        }
+                        *reinterpret_cast<f32x4*>(dpmL + jl * A + a) = acc;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    *reinterpret_cast<f32x4*>(redL + gid * A + sub * 4 + 64 * k) = dq[k];
+                    *reinterpret_cast<f32x4*>(redL + (32 + gid) * A + sub * 4 + 64 * k) = dv[k];
+                }
+            }
+            __syncthreads();
+            if (tid < A) {
+                float sq = 0.f, sv = 0.f;
+#pragma unroll
+                for (int k = 0; k < 32; ++k) { sq += redL[k * A + tid]; sv += redL[(32 + k) * A + tid]; }
+                dqoL[tid] = sq;
+                dvaL[tid] += sv;
+            }
+            __syncthreads();
+            if (tid < A / 4) {
+                const f32x4 q4 = *reinterpret_cast<const f32x4*>(dqoL + tid * 4);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q4), rsQ, (unsigned)((((as * 2 + split) * B + ab_) * A + tid * 4) * 4), 0, SC1);
+            }
+            publish(CNT(4 + as * 2 + ab_ / 32));
+            if (tid < A) AS.dq_out[((long)t * B + ab_) * 2 * A + split * A + tid] = dqoL[tid];
+            if (t > d.t0) load_ain(t - 1, tid);
+        }
+        // ======================================================================================= P(t)
+        if (hasP) {
+            float in[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) in[i] = pin[i];
+            if (wave == 0) {
+                bool ok = poll_counter(CNT(4 + ps * 2 + rt), (ep + 1) * (unsigned)(min(32, B - rt * 32) * 2), d.err, 8u);
+                if (ok && ep > 0) ok = poll_counter(CNT(8 + ps * 16 + u0 / ANC), ep * (unsigned)AKP, d.err, 9u);
+                if (!ok && lane == 0) *abortw = 1;
+            }
+            __syncthreads();
+            if (*abortw) return;
+            // dq rows of this row tile (two position splits summed), K-split partials of dx_h(t+1)
+            {
+                u32x4 qv[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int idx = tv + i * NTH, row = idx / (A / 4), a4 = (idx % (A / 4)) * 4;
+                    const int b = min(rt * 32 + row, B - 1);
+#pragma unroll
+                    for (int sp = 0; sp < 2; ++sp)
+                        qv[i][sp] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, (unsigned)((((ps * 2 + sp) * B + b) * A + a4) * 4), 0, SC1);
+                }
+                float pv[AKP] = {0.f, 0.f, 0.f, 0.f};
+                if (ep > 0) {
+                    const unsigned off = (unsigned)((t + 1) & 1) * pbh_half + (unsigned)ps * pbh_s + (unsigned)((((ug * MT + rt) * 32 + (tv >> 4)) * PU + (tv & 15)) * 4);
+#pragma unroll
+                    for (int z = 0; z < AKP; ++z) pv[z] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsH, off + z * pbh_kp, 0, SC1));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int idx = tv + i * NTH, row = idx / (A / 4), a4 = (idx % (A / 4)) * 4;
+                    *reinterpret_cast<f32x4*>(dqL + row * (A + 4) + a4) = __builtin_bit_cast(f32x4, qv[i][0]) + __builtin_bit_cast(f32x4, qv[i][1]);
+                }
+                in[0] += (pv[0] + pv[1]) + (pv[2] + pv[3]);
+            }
+            __syncthreads();
+            float dh = in[0];
+            {   // + dq . Wq[:, unit]   (attention.py:68: the query projection's input gradient)
+                const float* qr = dqL + (tid >> 4) * (A + 4);
+                const float* wr = wqL + (tid & 15);
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                for (int a = 0; a < A; a += 4) {
+                    a0 += qr[a] * wr[a * (PU + 1)]; a1 += qr[a + 1] * wr[(a + 1) * (PU + 1)];
+                    a2 += qr[a + 2] * wr[(a + 2) * (PU + 1)]; a3 += qr[a + 3] * wr[(a + 3) * (PU + 1)];
+                }
+                dh += (a0 + a1) + (a2 + a3);
+            }
+            float dcs = ep > 0 ? dc : 0.f;
+            if (d.drop_p > 0.f) {
+                const uint32_t idx = (uint32_t)(((long)t * B + pb) * H + pu);
+                dh = rng_keep(kh, idx, d.drop_p) ? dh * dscale : 0.f;
+                dcs = rng_keep(kc, idx, d.drop_p) ? dcs * dscale : 0.f;
+            }
+            const float ig = in[1], fg = in[2], gg = in[3], og = in[4];
+            const float tc = tanhf(in[5]);
+            const float dcn = dcs + dh * og * (1.0f - tc * tc);
+            float dgv[4] = {dcn * gg * ig * (1.0f - ig), dcn * in[6] * fg * (1.0f - fg), dcn * ig * (1.0f - gg * gg), dh * tc * og * (1.0f - og)};
+            if (pb >= B) { dgv[0] = dgv[1] = dgv[2] = dgv[3] = 0.f; }
+            dc = dcn * fg;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dgL[(g * 32 + (tid >> 4)) * (PU + 4) + (tid & 15)] = dgv[g];
+            __syncthreads();
+            if (wave < 4) {
+                const float* hp = dgL + (wave * 32 + r) * (PU + 4) + hk * 8;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(hp), hi = *reinterpret_cast<const f32x4*>(hp + 4);
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { o[j] = (__bf16)lo[j]; o[4 + j] = (__bf16)hi[j]; }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsX,
+                    (unsigned)((t & 1) * d.NS + ps) * xs + (unsigned)((((wave * H + u0) / 16) * MT + rt) * 1024 + lane * 16), 0, SC1);
+            }
+            publish(CNT(ps));
+            {
+                const int b = rt * 32 + (tv >> 4), u = u0 + (tv & 15);
+                if (b < B) {
+                    float* gp = PS.dg + ((long)t * B + b) * K4 + u;
+                    gp[0] = dgv[0]; gp[H] = dgv[1]; gp[2 * H] = dgv[2]; gp[3 * H] = dgv[3];
+                }
+                if (t > d.t0) load_pin(t - 1, tv);
+            }
+        }
+        // ======================================================================================= G(t)
+        if (hasG && t > 0) {
+            if (wave == 0 && !poll_counter(CNT(gs), (ep + 1) * (unsigned)nPs, d.err, 10u) && lane == 0) *abortw = 1;
+            __syncthreads();
+            if (*abortw) return;
+            const unsigned xb = (unsigned)((t & 1) * d.NS + gs) * xs + (unsigned)lane * 16u;
+            u32x4 af[MT][8];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    af[m][i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xb + (unsigned)(((kp * (H / 16) + wave * 8 + i) * MT + m) * 1024), 0, SC1);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[m][i]), W[c][i], acc, 0, 0, 0);
+                    if (m + c > 0) __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) partL[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk) * PPR + r] = acc[e];
+                    __syncthreads();
+                    if (tv < 256) {
+                        const int row = tv >> 3, c4 = (tv & 7) * 4;
+                        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int w = 0; w < NWV; ++w) sum += *reinterpret_cast<const f32x4*>(partL + (w * 32 + row) * PPR + c4);
+                        const int col = nt * ANC + c * 32 + c4;                 // column of [ctx | h]
+                        if (nt < NTC) {
+                            const int b = m * 32 + row;
+                            if (b < B)
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sum), rsC,
+                                    (unsigned)(t & 1) * pbc_half + (unsigned)gs * pbc_s + (unsigned)kp * pbc_kp + (unsigned)((b * E + col) * 4), 0, SC1);
+                        } else {
+                            const int u = col - E;
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sum), rsH,
+                                (unsigned)(t & 1) * pbh_half + (unsigned)gs * pbh_s + (unsigned)kp * pbh_kp +
+                                (unsigned)(((((u / PU) * MT + m) * 32 + row) * PU + (u % PU)) * 4), 0, SC1);
+                        }
+                    }
+                }
+            publish(nt < NTC ? CNT(2 + gs) : CNT(8 + gs * 16 + (nt - NTC)));
+        }
+    }
+    // ---------------------------------------------------------------- A epilogue: the accumulators leave LDS
+    if (hasA) {
+        for (int a = tid; a < A; a += NTH) AS.dv_acc[((long)split * B + ab_) * A + a] = dvaL[a];
+        for (int i = tid; i < len * (A / 4); i += NTH) {
+            const int jl = i / (A / 4), a4 = (i % (A / 4)) * 4;
+            *reinterpret_cast<f32x4*>(AS.dpm_acc + ((long)ab_ * Tin + jb + jl) * A + a4) = *reinterpret_cast<const f32x4*>(dpmL + jl * A + a4);
+        }
+    }
+}
+
 }  // namespace
 
 bool chain_bwd_plan(ChainBwdDesc& d) {
-    if (d.kind != CHAIN_LSTM || d.H != 1024 || d.B < 1 || d.B > 64) return false;
+    if (d.H != 1024 || d.B < 1 || d.B > 64) return false;
     if (chain_device_cus() < 256) return false;
-    return true;
+    if (d.kind == CHAIN_LSTM) return true;
+    if (d.kind != CHAIN_SMA || d.E != 512 || d.A != 128 || d.NS < 1 || d.NS > 2) return false;
+    int tc = 0;
+    for (int s = 0; s < d.NS; ++s) {
+        if (d.st[s].Tin < 16) return false;                          // (two position splits per item, as the launch path at these sizes)
+        tc = std::max(tc, (((d.st[s].Tin + 1) / 2) + 3) & ~3);
+    }
+    d.lds_Tc = tc;
+    return (size_t)bwd_lds_of(d.A, d.E, tc, (d.B + 31) / 32).total * sizeof(float) <= 160 * 1024;
 }
 
 size_t chain_bwd_exchange_bytes(const ChainBwdDesc& d, size_t* x_bytes, size_t* pb_bytes) {
@@ -207,14 +606,39 @@ size_t chain_bwd_exchange_bytes(const ChainBwdDesc& d, size_t* x_bytes, size_t* 
     return *x_bytes + *pb_bytes;
 }
 
+size_t chain_bwd_att_exchange_bytes(const ChainBwdDesc& d, size_t* x_bytes, size_t* pbh_bytes, size_t* pbc_bytes, size_t* dqx_bytes, size_t* carry_bytes) {
+    const size_t MT = (d.B + 31) / 32, al = 255;
+    *x_bytes = (size_t)2 * d.NS * (4 * d.H / 16) * MT * 1024;
+    *pbh_bytes = (size_t)2 * d.NS * AKP * (d.H / PU) * MT * 32 * PU * sizeof(float);
+    *pbc_bytes = ((size_t)2 * d.NS * AKP * d.B * d.E * sizeof(float) + al) & ~al;
+    *dqx_bytes = ((size_t)d.NS * 2 * d.B * d.A * sizeof(float) + al) & ~al;
+    *carry_bytes = ((size_t)2 * d.NS * d.B * sizeof(float) + al) & ~al;
+    return *x_bytes + *pbh_bytes + *pbc_bytes + *dqx_bytes + *carry_bytes;
+}
+
 int chain_bwd(const ChainBwdDesc& d, hipStream_t s) {
     T2_REQUIRE(d.t1 > d.t0 && d.t0 >= 0, "chain_bwd: bad step range [%d,%d)", d.t0, d.t1);
     T2_REQUIRE(d.X && d.PB && d.cnt && d.err, "chain_bwd: exchange buffers missing");
-    T2_REQUIRE(d.kind == CHAIN_LSTM, "chain_bwd: kind %d not covered", d.kind);
     const int MT = (d.B + 31) / 32;
+    T2_CHECK_HIP(hipMemsetAsync(d.cnt, 0, kChainBwdCntBytes, s));
+    if (d.kind == CHAIN_SMA) {
+        T2_REQUIRE(d.t0 == 0 && d.t1 == d.T, "chain_bwd: the attention chain runs its whole step range in one launch");
+        T2_REQUIRE(d.PBC && d.DQX && d.CARRYX, "chain_bwd: exchange buffers missing");
+        const size_t smem = (size_t)bwd_lds_of(d.A, d.E, d.lds_Tc, MT).total * sizeof(float);
+        const int grid = std::max(std::max(d.NS * (d.E + d.H) / ANC * AKP, d.NS * (d.H / PU) * MT), d.NS * d.B * 2);
+        if (MT == 1) {
+            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_bwd_sma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(chain_bwd_sma_kernel<1>, dim3(grid), dim3(NTH), smem, s, d);
+        } else {
+            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_bwd_sma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(chain_bwd_sma_kernel<2>, dim3(grid), dim3(NTH), smem, s, d);
+        }
+        T2_LAUNCH_CHECK();
+        return 0;
+    }
+    T2_REQUIRE(d.kind == CHAIN_LSTM, "chain_bwd: kind %d not covered", d.kind);
     const size_t smem = (size_t)(4 + NWV * MT * 32 * PPR) * sizeof(float);
     const int grid = (d.H / GNC) * GKP;
-    T2_CHECK_HIP(hipMemsetAsync(d.cnt, 0, kChainBwdCntBytes, s));
     if (MT == 1) {
         T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_bwd_lstm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(chain_bwd_lstm_kernel<1>, dim3(grid), dim3(NTH), smem, s, d);

@@ -227,15 +227,31 @@ struct ChainBwdStream {
     float* dg;                            // out: gate pre-activation gradients [T][B][4H]
     float* dc_state;                      // [B][H] dL/dc carried between launches of one pass (chunked ranges)
     uint32_t site_h, site_c;
+    // attention chain (CHAIN_SMA): gradient sources on ctx(t), saved forward quantities, parameters, outputs
+    const float* dctx_a; long lddctx_a;   // dctx_a[(t*B + b)*ld + c]: through the projections / decoder LSTM (dDOUT)
+    const float* dctx_b; long lddctx_b;   // through the decoder-LSTM input (dDIN)
+    const float* dalign;                  // [B,T,Tin] external gradient on the alignments (nullable)
+    const float* qs;                      // [T][B][A] processed queries
+    const float* pm; const float* memory; int Tin;   // [B,Tin,A], [B,Tin,E]
+    const float* psel; const float* align;           // [B,T,Tin] selection probabilities, alignments
+    const float* v; const float* wq;      // [A], [A][H]
+    float* dctx_out;                      // [T][B][E] total context gradient (d(memory) GEMM)
+    float* dq_out;                        // [T][B][2A] one partial per position split (dWq GEMM)
+    float* dv_acc;                        // [2][B][A]
+    float* dpm_acc;                       // [B][Tin][A]
 };
 struct ChainBwdDesc {
     ChainBwdStream st[2]; int NS, B, T, t0, t1, H, kind;
+    int E, A;
     float drop_p; uint64_t seed;
     unsigned char* X; unsigned char* PB; unsigned* cnt; unsigned* err; unsigned pb_bytes;   // exchange: dg fragments, K-split partials
+    unsigned char* PBC; unsigned pbc_bytes; float* DQX; float* CARRYX;                       // attention chain: ctx partials, dq partials, boundary carry
+    int lds_Tc;                                                                              // positions per split of the longest memory (LDS carve)
 };
 constexpr size_t kChainBwdCntBytes = 64 * 128;     // arrival counters, one per 128-byte line
 bool chain_bwd_plan(ChainBwdDesc& d);
 size_t chain_bwd_exchange_bytes(const ChainBwdDesc& d, size_t* x_bytes, size_t* pb_bytes);
+size_t chain_bwd_att_exchange_bytes(const ChainBwdDesc& d, size_t* x_bytes, size_t* pbh_bytes, size_t* pbc_bytes, size_t* dqx_bytes, size_t* carry_bytes);
 int chain_bwd(const ChainBwdDesc& d, hipStream_t s);
 
 // ------------------------------------------------------------------ decode-step tail (infer.hip)
