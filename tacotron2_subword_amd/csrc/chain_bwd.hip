@@ -19,6 +19,25 @@
 
 #include "chain_common.h"
 
+#ifdef T2_STAMPS
+__device__ unsigned long long t2_chain_bwd_stamps[256 * 16];
+extern "C" int t2_debug_read_chain_bwd_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(t2_chain_bwd_stamps), sizeof(unsigned long long) * n);
+}
+extern "C" int t2_debug_clear_chain_bwd_stamps(void) {
+    static unsigned long long z[256 * 16];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(t2_chain_bwd_stamps), z, sizeof(z));
+}
+#define T2_BSTAMP(i)                                                                              \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); stamp_acc[i] += n_ - stamp_last; stamp_last = n_; } \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+#else
+#define T2_BSTAMP(i)
+#endif
+
 namespace t2 {
 
 namespace {
@@ -333,6 +352,10 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
     const RngKey kh = rng_key(d.seed, PS.site_h), kc = rng_key(d.seed, PS.site_c);
     const float dscale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
 
+#ifdef T2_STAMPS
+    unsigned long long stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int t = d.t1 - 1; t >= d.t0; --t) {
         const unsigned ep = (unsigned)(d.t1 - 1 - t);
         int tv = threadIdx.x;
@@ -340,6 +363,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
         // ======================================================================================= A(t)
         if (hasA) {
             const int tid = tv, lane = tid & 63, wave = tid >> 6;
+            T2_BSTAMP(15);
             float in[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) in[i] = ain[i];
@@ -348,6 +372,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
                 __syncthreads();
                 if (*abortw) return;
             }
+            T2_BSTAMP(0);
             // total gradient on ctx(t): direct sources + the four K-split partials of dx_ctx(t+1)
             float boundary = 0.f;                                       // carry of position je, owned by the other split
             if (tid < E) {
@@ -368,6 +393,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
             if (tid < len) { psL[tid] = in[1]; apL[tid] = in[2]; }
             if (tid == 0) { gL[ng] = 0.f; if (je < Tin) carryL[len] = boundary; }
             __syncthreads();
+            T2_BSTAMP(1);
             // g_j = dctx . memory_j + dalign_j + carry_j: one wave per position, lanes stride the E columns 8 at a time
             for (int jl = wave; jl < ng; jl += NWV) {
                 float sum = 0.f;
@@ -399,6 +425,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, co), rsK, (unsigned)(((t & 1) * d.NS + as) * B + ab_) * 4u, 0, SC1);
             }
             __syncthreads();
+            T2_BSTAMP(2);
             // energies backward: 16 lanes per position, each lane owns channels sub*4 + 64*k
             {
                 const int gid = tid >> 4, sub = tid & 15;
@@ -440,7 +467,9 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
                 const f32x4 q4 = *reinterpret_cast<const f32x4*>(dqoL + tid * 4);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q4), rsQ, (unsigned)((((as * 2 + split) * B + ab_) * A + tid * 4) * 4), 0, SC1);
             }
+            T2_BSTAMP(3);
             publish(CNT(4 + as * 2 + ab_ / 32));
+            T2_BSTAMP(4);
             if (tid < A) AS.dq_out[((long)t * B + ab_) * 2 * A + split * A + tid] = dqoL[tid];
             if (t > d.t0) load_ain(t - 1, tid);
         }
@@ -456,6 +485,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
             }
             __syncthreads();
             if (*abortw) return;
+            T2_BSTAMP(5);
             // dq rows of this row tile (two position splits summed), K-split partials of dx_h(t+1)
             {
                 u32x4 qv[2][2];
@@ -516,7 +546,9 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsX,
                     (unsigned)((t & 1) * d.NS + ps) * xs + (unsigned)((((wave * H + u0) / 16) * MT + rt) * 1024 + lane * 16), 0, SC1);
             }
+            T2_BSTAMP(6);
             publish(CNT(ps));
+            T2_BSTAMP(7);
             {
                 const int b = rt * 32 + (tv >> 4), u = u0 + (tv & 15);
                 if (b < B) {
@@ -531,6 +563,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
             if (wave == 0 && !poll_counter(CNT(gs), (ep + 1) * (unsigned)nPs, d.err, 10u) && lane == 0) *abortw = 1;
             __syncthreads();
             if (*abortw) return;
+            T2_BSTAMP(8);
             const unsigned xb = (unsigned)((t & 1) * d.NS + gs) * xs + (unsigned)lane * 16u;
             u32x4 af[MT][8];
 #pragma unroll
@@ -570,9 +603,15 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
                         }
                     }
                 }
+            T2_BSTAMP(9);
             publish(nt < NTC ? CNT(2 + gs) : CNT(8 + gs * 16 + (nt - NTC)));
+            T2_BSTAMP(10);
         }
     }
+#ifdef T2_STAMPS
+    if (tid == 0)
+        for (int i = 0; i < 16; ++i) t2_chain_bwd_stamps[wg * 16 + i] += stamp_acc[i];
+#endif
     // ---------------------------------------------------------------- A epilogue: the accumulators leave LDS
     if (hasA) {
         for (int a = tid; a < A; a += NTH) AS.dv_acc[((long)split * B + ab_) * A + a] = dvaL[a];

@@ -139,6 +139,52 @@ def test_conv_bn_stack_bf16_staged_vs_converting(env, training):
         assert rel(a, b) < 2e-4
 
 
+def test_conv_bf16_implicit_gemm_vs_fp64_on_rounded_operands(env):
+    """The bf16-source implicit-conv path (frames staged once as bf16, taps as row shifts, im2col transpose written out
+    for d(weight)) against an INDEPENDENT reference: F.conv1d in fp64 on bf16-rounded x, w (forward) and bf16-rounded dz
+    (both backward products) — the yardstick test_gemm_bf16_staged_operands uses for the plain GEMM.  Whole-tile shape
+    (B*T = 256 rows, 128 -> 256 channels, k = 5), utterance edges checked on their own.  Reference semantics: Conv1d of
+    model.py:34-70 via layers.py:21-39.  BatchNorm in eval mode with unit statistics is the identity, so y = conv + bias."""
+    import torch.nn.functional as F
+    L, blocks, ops = env
+    g = torch.Generator().manual_seed(23)
+    B, T, Cin, Cout = 2, 128, 128, 256
+    conv = torch.nn.Conv1d(Cin, Cout, 5, padding=2).cuda()
+    bn = torch.nn.BatchNorm1d(Cout).cuda().eval()
+    bn.running_mean.zero_(); bn.running_var.fill_(1.0 - bn.eps)
+    x0 = torch.randn(B, T, Cin, generator=g).cuda()
+    R = torch.randn(B, T, Cout, generator=g).cuda()
+    L.set_precision("bf16")
+    try:
+        xd = x0.clone().requires_grad_(True)
+        y = blocks.conv_bn_stack(xd, [(conv, bn)], [blocks.ACT_NONE], training=False, drop_p=0.0, seed=1, site0=L.SITE["ENC0"])
+        (y * R).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        L.set_precision("f32")
+    rb = lambda t: t.detach().bfloat16().double().cpu()
+    xb = rb(x0).permute(0, 2, 1).requires_grad_(True)                    # [B,Cin,T], bf16-rounded values in fp64
+    wb = rb(conv.weight).requires_grad_(True)
+    z = F.conv1d(xb, wb, conv.bias.detach().double().cpu(), padding=2)    # [B,Cout,T]
+    inv = 1.0 / torch.sqrt(bn.running_var.double().cpu() + bn.eps)
+    y_ref = (z * inv[None, :, None]).permute(0, 2, 1)
+    K = 5 * Cin
+    tol = 2e-3 * max(1.0, K ** 0.5 / 8)
+    err = (y.double().cpu() - y_ref).abs()
+    edges = torch.tensor([0, 1, T - 2, T - 1])
+    assert float(err.max()) < tol and float(err[:, edges].max()) < tol, (float(err.max()), float(err[:, edges].max()))
+    # backward: both products read bf16(dz); dz = dy * gamma * invstd (eval-mode BatchNorm)
+    dz = rb(R * (bn.weight.detach() * (1.0 / torch.sqrt(bn.running_var + bn.eps)))[None, None, :]).permute(0, 2, 1)
+    gx, gw = torch.autograd.grad(z, (xb, wb), dz)
+    ex = (xd.grad.double().cpu() - gx.permute(0, 2, 1)).abs()
+    assert float(ex.max()) < 2e-3 * max(1.0, (5 * Cout) ** 0.5 / 8) and float(ex[:, edges].max()) < 2e-3 * max(1.0, (5 * Cout) ** 0.5 / 8)
+    ew = (conv.weight.grad.double().cpu() - gw).abs()
+    assert float(ew.max()) < 2e-3 * max(1.0, (B * T) ** 0.5 / 8), float(ew.max())
+    # the edge taps of d(weight) see the zero padding: a tap-wise check that no frame of the neighbouring utterance leaks in
+    for tap in (0, 4):
+        assert float(ew[:, :, tap].max()) < 2e-3 * max(1.0, (B * T) ** 0.5 / 8)
+
+
 @pytest.mark.parametrize("packed", [True, False])
 def test_bilstm_vs_oracle(env, packed):
     L, blocks, ops = env
