@@ -237,7 +237,7 @@ __host__ __device__ inline BwdLds bwd_lds_of(int A, int E, int Tc, int MT) {
     m.ab = take(4); m.v = take(A); m.q = take(A); m.dctx = take(E);
     m.g = take(Tc + 8); m.de = take(Tc + 8); m.ps = take(Tc + 8); m.ap = take(Tc + 8); m.carry = take(Tc + 8);
     m.dva = take(A); m.dqo = take(A);
-    m.wq = take(A * (PU + 1));
+    m.wq = take(PU * (A + 4));
     m.pm = take(Tc * A); m.dpm = take(Tc * A); m.mem = take((Tc + 1) * E / 2);
     const int sg = NWV * 32 * PPR, sp = 32 * (A + 4) + 4 * 32 * (PU + 4), sa = 2 * 32 * A;
     m.scratch = take(sg > sp ? (sg > sa ? sg : sa) : (sp > sa ? sp : sa));
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
         pin[6] = t > 0 ? PS.c_out[((long)(t - 1) * B + b) * H + u] : 0.f;
     };
     if (hasP) {
-        for (int i = tid; i < A * PU; i += NTH) wqL[(i / PU) * (PU + 1) + i % PU] = PS.wq[(long)(i / PU) * H + u0 + i % PU];
+        for (int i = tid; i < A * PU; i += NTH) wqL[(i % PU) * (A + 4) + i / PU] = PS.wq[(long)(i / PU) * H + u0 + i % PU];      // [unit][a]
         load_pin(d.t1 - 1, tid);
     }
     // ---------------------------------------------------------------- A setup: resident rows, zeroed accumulators
@@ -449,16 +449,25 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    *reinterpret_cast<f32x4*>(redL + gid * A + sub * 4 + 64 * k) = dq[k];
-                    *reinterpret_cast<f32x4*>(redL + (32 + gid) * A + sub * 4 + 64 * k) = dv[k];
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {                       // the wave's 4 position groups (lanes 16 apart), fixed order
+                        dq[k][c] += __shfl_xor(dq[k][c], 16, 64); dq[k][c] += __shfl_xor(dq[k][c], 32, 64);
+                        dv[k][c] += __shfl_xor(dv[k][c], 16, 64); dv[k][c] += __shfl_xor(dv[k][c], 32, 64);
+                    }
+                if (lane < 16) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        *reinterpret_cast<f32x4*>(redL + wave * A + sub * 4 + 64 * k) = dq[k];
+                        *reinterpret_cast<f32x4*>(redL + (NWV + wave) * A + sub * 4 + 64 * k) = dv[k];
+                    }
                 }
             }
             __syncthreads();
             if (tid < A) {
                 float sq = 0.f, sv = 0.f;
 #pragma unroll
-                for (int k = 0; k < 32; ++k) { sq += redL[k * A + tid]; sv += redL[(32 + k) * A + tid]; }
+                for (int k = 0; k < NWV; ++k) { sq += redL[k * A + tid]; sv += redL[(NWV + k) * A + tid]; }
                 dqoL[tid] = sq;
                 dvaL[tid] += sv;
             }
@@ -512,15 +521,13 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
             }
             __syncthreads();
             float dh = in[0];
-            {   // + dq . Wq[:, unit]   (attention.py:68: the query projection's input gradient)
-                const float* qr = dqL + (tid >> 4) * (A + 4);
-                const float* wr = wqL + (tid & 15);
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                for (int a = 0; a < A; a += 4) {
-                    a0 += qr[a] * wr[a * (PU + 1)]; a1 += qr[a + 1] * wr[(a + 1) * (PU + 1)];
-                    a2 += qr[a + 2] * wr[(a + 2) * (PU + 1)]; a3 += qr[a + 3] * wr[(a + 3) * (PU + 1)];
-                }
-                dh += (a0 + a1) + (a2 + a3);
+            {   // + dq . Wq[:, unit]   (attention.py:68: the query projection's input gradient): 16-byte LDS reads of both rows
+                const float* qr = dqL + (tid >> 4) * (A + 4);          // (broadcast across the 16 units of a row)
+                const float* wr = wqL + (tid & 15) * (A + 4);          // pitch A+4: the 16 rows start 4 banks apart
+                f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+                for (int a = 0; a < A; a += 4) acc4 += *reinterpret_cast<const f32x4*>(qr + a) * *reinterpret_cast<const f32x4*>(wr + a);
+                dh += (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
             }
             float dcs = ep > 0 ? dc : 0.f;
             if (d.drop_p > 0.f) {
