@@ -73,7 +73,7 @@ __host__ __device__ inline Geo geo_of(const ChainDesc& d, int UT, int RT) {
 }
 
 // LDS carve (floats).  Persistent part first, then a scratch area shared by the two phases.
-struct Lds { int ab, v, ap, cum, q, e, an, cs, pm, mem, scratch, total; };
+struct Lds { int ab, v, ap, cum, q, e, an, cs, pm, mem, convw, dense, loc, wpad, pa, scratch, total; };
 __host__ __device__ inline Lds lds_of(const ChainDesc& d, int UT, int RT, int Tin, int Jp, int Jm) {
     Lds m; int o = 0;
     auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
@@ -83,10 +83,20 @@ __host__ __device__ inline Lds lds_of(const ChainDesc& d, int UT, int RT, int Ti
         m.v = take(d.A); m.ap = take(Tp + 4); m.cum = take(Tp + 4); m.q = take(d.A); m.e = take(Tp + 4); m.an = take(Tp + 4); m.cs = take(EC);
         m.pm = take(Jp * d.A); m.mem = take(Jm * EC / 2);
     } else { m.v = m.ap = m.cum = m.q = m.e = m.an = m.cs = m.pm = m.mem = o; }
+    m.convw = m.dense = o;
+    if (d.kind == CHAIN_LSA) { m.convw = take(d.F * 2 * d.Kc); m.dense = take(d.A * (d.F + 1)); }   // location layer weights, resident
     const int lpart = NWV * 32 * PPR, lhs = RT * 32 * (UT * 8 + 4), lq = d.kind == CHAIN_LSTM ? 0 : RT * 32 * (d.A + 4);
     const int lphase = (lpart > lq ? lpart : lq) + lhs;
-    const int aphase = d.kind == CHAIN_LSTM ? 0 : 16 * d.A + NWV * EC;
+    int aphase = d.kind == CHAIN_LSTM ? 0 : 16 * d.A + NWV * EC;
+    m.loc = m.wpad = m.pa = 0;
+    if (d.kind == CHAIN_LSA) {                               // per-step location features behind the reduction buffers
+        const int TwP = (Tin + d.Kc - 1 + 4 + 3) & ~3;
+        m.loc = aphase; aphase += (Tin * (d.F + 1) + 3) & ~3;
+        m.wpad = aphase; aphase += 2 * TwP;
+        m.pa = aphase; aphase += Tin * (d.A + 8);
+    }
     m.scratch = take(lphase > aphase ? lphase : aphase);
+    m.loc += m.scratch; m.wpad += m.scratch; m.pa += m.scratch;
     m.total = o;
     return m;
 }
@@ -123,6 +133,9 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
     float* hsL = smem + M.scratch + (NWV * 32 * PPR > lq ? NWV * 32 * PPR : lq);   // [RT*32][HSP]
     float* redL = smem + M.scratch;                                    // [16][A]             (A phase)
     float* credL = smem + M.scratch + 16 * A;                          // [NWV][EC]
+    float* convwL = smem + M.convw; float* denseL = smem + M.dense;    // LSA: [F][2][Kc], [A][F+1]
+    float* locL = smem + M.loc; float* wpadL = smem + M.wpad; float* paL = smem + M.pa;   // LSA: [Tin][F+1], [2][TwP], [Tin][A+8]
+    (void)convwL; (void)denseL; (void)locL; (void)wpadL; (void)paL;
     (void)cumL; (void)qsL; (void)redL; (void)credL; (void)csL; (void)eL; (void)anL; (void)qL; (void)vL; (void)pmL; (void)memL;
 
     auto rsX = __builtin_amdgcn_make_buffer_rsrc(d.X, 0, (int)(2u * d.NS * G.xs_bytes), 0x00020000);
@@ -187,6 +200,11 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             const f32x4 m4 = *reinterpret_cast<const f32x4*>(AS.memory + ((long)ab_ * Tin + j) * d.E + c0 + c4);
             bf16x4 o; o[0] = (__bf16)m4[0]; o[1] = (__bf16)m4[1]; o[2] = (__bf16)m4[2]; o[3] = (__bf16)m4[3];
             *reinterpret_cast<bf16x4*>(memL + j * EC + c4) = o;
+        }
+        if (KIND == CHAIN_LSA) {
+            const int F = d.F, Kc = d.Kc, F1 = F + 1;
+            for (int i = tid; i < F * 2 * Kc; i += NTH) convwL[i] = AS.loc_conv[i];
+            for (int i = tid; i < A * F1; i += NTH) denseL[i] = (i % F1) < F ? AS.loc_dense[(i / F1) * F + (i % F1)] : 0.f;
         }
         alen = AS.lengths ? AS.lengths[ab_] : Tin;
         if (d.max_pos > 0) alen = min(alen, d.max_pos);
@@ -450,6 +468,53 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 qL[tid] = sum;
                 if (part == 0) AS.qs[((long)t * B + ab_) * A + tid] = sum;
             }
+            if (KIND == CHAIN_LSA) {
+                // ---- location features of [w_{t-1}; cum_{t-1}] (attention.py:7-23): conv (2 -> F channels, Kc taps, zero padded),
+                // then the dense layer on the matrix cores (exact fp32 fma chains), as attention.hip's LSA step
+                const int F = d.F, Kc = d.Kc, F1 = F + 1, pad = (Kc - 1) / 2, Tw = Tin + Kc - 1, TwP = (Tw + 4 + 3) & ~3;
+                for (int i = tid; i < 2 * TwP; i += NTH) {
+                    const int c = i / TwP, j = i % TwP - pad;
+                    wpadL[i] = (j >= 0 && j < Tin) ? (c == 0 ? apL[j] : cumL[j]) : 0.f;
+                }
+                __syncthreads();
+                const int nj4 = (Tin + 3) / 4;
+                for (int i = tid; i < nj4 * F; i += NTH) {              // one thread per (filter, 4 positions): sliding window in registers
+                    const int f = i % F, j0 = (i / F) * 4;
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                    for (int c = 0; c < 2; ++c) {
+                        const float* w = convwL + (f * 2 + c) * Kc;
+                        const float* xw = wpadL + c * TwP + j0;
+                        float x0 = xw[0], x1 = xw[1], x2 = xw[2];
+                        for (int k = 0; k < Kc; ++k) {
+                            const float x3 = xw[k + 3], wk = w[k];
+                            a0 += wk * x0; a1 += wk * x1; a2 += wk * x2; a3 += wk * x3;
+                            x0 = x1; x1 = x2; x2 = x3;
+                        }
+                    }
+                    locL[j0 * F1 + f] = a0;
+                    if (j0 + 1 < Tin) locL[(j0 + 1) * F1 + f] = a1;
+                    if (j0 + 2 < Tin) locL[(j0 + 2) * F1 + f] = a2;
+                    if (j0 + 3 < Tin) locL[(j0 + 3) * F1 + f] = a3;
+                }
+                for (int j = tid; j < Tin; j += NTH) locL[j * F1 + F] = 0.f;         // pad column (K rounded up to even)
+                __syncthreads();
+                const int r_ = lane & 31, h_ = lane >> 5;
+                const int njt = (Tin + 31) / 32, nat = A / 32, Ke = (F + 1) & ~1;
+                for (int tile = wave; tile < njt * nat; tile += NWV) {
+                    const int jt = tile / nat, at = tile % nat;
+                    const float* lr = locL + min(jt * 32 + r_, Tin - 1) * F1 + h_;
+                    const float* dr = denseL + (at * 32 + r_) * F1 + h_;
+                    f32x16 acc;
+#pragma unroll
+                    for (int e2 = 0; e2 < 16; ++e2) acc[e2] = 0.f;
+                    for (int kk = 0; kk < Ke; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lr[kk], dr[kk], acc, 0, 0, 0);
+#pragma unroll
+                    for (int e2 = 0; e2 < 16; ++e2) {
+                        const int row = jt * 32 + (e2 & 3) + 8 * (e2 >> 2) + 4 * h_;
+                        if (row < Tin) paL[row * (A + 8) + at * 32 + r_] = acc[e2];
+                    }
+                }
+            }
             __syncthreads();
             T2_CSTAMP(8);
             // ---- energies e_j = v . tanh(q + pm_j) = sum(v) - 2 sum_a v_a / (exp(2 (q_a + pm_ja)) + 1): 16 lanes per position,
@@ -468,7 +533,11 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 constexpr float K2 = 2.0f * 1.44269504088896341f;
                 // LDS-resident rows and L2 rows go through separate loops: one loop with a choice per row makes hipcc
                 // select between the two pointers and read both through flat_load
-                auto dot = [&](const f32x4 (&pv)[2]) {
+                auto dot = [&](f32x4 (&pv)[2], int j) {
+                    if (KIND == CHAIN_LSA) {                             // + dense(conv([w_prev; w_cum]))_j   (attention.py:20-23, 73)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) pv[k] += *reinterpret_cast<const f32x4*>(paL + j * (A + 8) + sub * 4 + 64 * k);
+                    }
                     float sum = 0.f;
 #pragma unroll
                     for (int k = 0; k < 2; ++k)
@@ -492,15 +561,15 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                         p0[k] = *reinterpret_cast<const f32x4*>(pmL + j * A + sub * 4 + 64 * k);
                         p1[k] = *reinterpret_cast<const f32x4*>(pmL + min(j1, nres - 1) * A + sub * 4 + 64 * k);
                     }
-                    finish(j, dot(p0));
-                    if (j1 < nres) finish(j1, dot(p1));
+                    finish(j, dot(p0, j));
+                    if (j1 < nres) finish(j1, dot(p1, min(j1, nres - 1)));
                 }
                 for (j = nres + gid; j < Tin; j += NTH / 16) {           // rows beyond the LDS budget: from L2
                     const float* pr = AS.pm + ((long)ab_ * Tin + j) * A + sub * 4;
                     f32x4 p0[2];
 #pragma unroll
                     for (int k = 0; k < 2; ++k) p0[k] = *reinterpret_cast<const f32x4*>(pr + 64 * k);
-                    finish(j, dot(p0));
+                    finish(j, dot(p0, j));
                 }
             }
             __syncthreads();
@@ -523,6 +592,43 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                     if (j > 0) a += apL[j - 1] * (1.0f - eL[j - 1]);
                     anL[j] = a;
                     if (part == 0) AS.align[((long)ab_ * d.T + t) * Tin + j] = a;
+                }
+            } else {
+                // masked softmax over the positions, cumulative weights (attention.py:76-85, model.py:358-361)
+                float maskv = AS.mask_value;
+                asm volatile("" : "+v"(maskv));
+                float mx = -INFINITY;
+                for (int j = tid; j < Tin; j += NTH) {
+                    float ev = eL[j];
+                    if (j >= alen) ev = maskv;
+                    eL[j] = ev;
+                    mx = fmaxf(mx, ev);
+                }
+                mx = wave_max(mx);
+                if (lane == 0) credL[wave] = mx;
+                __syncthreads();
+                mx = credL[0];
+#pragma unroll
+                for (int w = 1; w < NWV; ++w) mx = fmaxf(mx, credL[w]);
+                float sum = 0.f;
+                for (int j = tid; j < Tin; j += NTH) { const float x = __expf(eL[j] - mx); eL[j] = x; sum += x; }
+                sum = wave_sum(sum);
+                __syncthreads();
+                if (lane == 0) credL[wave] = sum;
+                __syncthreads();
+                sum = credL[0];
+#pragma unroll
+                for (int w = 1; w < NWV; ++w) sum += credL[w];
+                const float inv = 1.0f / sum;
+                for (int j = tid; j < Tin; j += NTH) {
+                    const float w = eL[j] * inv;
+                    anL[j] = w;
+                    const float cm = cumL[j] + w;
+                    cumL[j] = cm;
+                    if (part == 0) {
+                        AS.align[((long)ab_ * d.T + t) * Tin + j] = w;
+                        AS.wcum[((long)ab_ * d.T + t) * Tin + j] = cm;
+                    }
                 }
             }
             __syncthreads();
@@ -602,7 +708,7 @@ int chain_device_cus() {
 bool chain_plan(ChainDesc& d) {
     if (d.H != 1024 || d.B < 1 || d.B > 128) return false;
     if (d.kind != CHAIN_LSTM && (d.E != 512 || d.A != 128 || d.NS < 1 || d.NS > 2)) return false;
-    if (d.kind == CHAIN_LSA) return false;                        // (location-sensitive variant: not yet in this kernel)
+    if (d.kind == CHAIN_LSA && (d.F + 1 > 64 || d.A % 32 != 0)) return false;
     const int MT = (d.B + 31) / 32;
     if (d.kind == CHAIN_LSTM) { d.UT = 1; d.RT = MT <= 2 ? MT : 2; d.CS = 1; d.NS = 1; }
     else {
@@ -659,7 +765,12 @@ int chain_fwd(const ChainDesc& d, hipStream_t s) {
         if (d.RT == 1) return chain_launch<1, 1, 0, CHAIN_LSTM>(d, s);
         return chain_launch<1, 2, 0, CHAIN_LSTM>(d, s);
     }
-    T2_REQUIRE(d.kind == CHAIN_SMA, "chain_fwd: attention kind %d not covered", d.kind);
+    T2_REQUIRE(d.kind == CHAIN_SMA || d.kind == CHAIN_LSA, "chain_fwd: attention kind %d not covered", d.kind);
+    if (d.kind == CHAIN_LSA) {
+        if (d.UT == 1 && d.RT == 1) return chain_launch<1, 1, 4, CHAIN_LSA>(d, s);
+        if (d.UT == 2 && d.RT == 1) return chain_launch<2, 1, 4, CHAIN_LSA>(d, s);
+        if (d.UT == 2 && d.RT == 2) return chain_launch<2, 2, 4, CHAIN_LSA>(d, s);
+    }
     if (d.UT == 1 && d.RT == 1) return chain_launch<1, 1, 4, CHAIN_SMA>(d, s);
     if (d.UT == 2 && d.RT == 1) return chain_launch<2, 1, 4, CHAIN_SMA>(d, s);
     if (d.UT == 2 && d.RT == 2) return chain_launch<2, 2, 4, CHAIN_SMA>(d, s);

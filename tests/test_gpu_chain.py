@@ -55,13 +55,14 @@ def _run(env, att, B, Tin, Tsub, T, chain, training, seed=11, ragged=True):
     return out, st, (W, P, dims, dp, mem, mems)
 
 
+@pytest.mark.parametrize("att", [SMA, LSA])
 @pytest.mark.parametrize("B,Tin,Tsub,T", [(3, 13, 9, 12), (33, 20, 11, 10), (64, 100, 60, 8), (128, 37, 22, 6)])
 @pytest.mark.parametrize("training", [False, True])
-def test_chain_matches_per_step_launches(env, B, Tin, Tsub, T, training):
+def test_chain_matches_per_step_launches(env, att, B, Tin, Tsub, T, training):
     """Every tiling (B <= 32: one row tile, 8 units per item, context in 4 parts; B <= 64: 16 units, 2 parts; B <= 128: two
     row tiles, whole context rows), ragged memory lengths, with and without LSTM-state dropout + SMA noise."""
-    ref, st0, _ = _run(env, SMA, B, Tin, Tsub, T, chain=False, training=training)
-    got, st1, _ = _run(env, SMA, B, Tin, Tsub, T, chain=True, training=training)
+    ref, st0, _ = _run(env, att, B, Tin, Tsub, T, chain=False, training=training)
+    got, st1, _ = _run(env, att, B, Tin, Tsub, T, chain=True, training=training)
     assert not any(st0) and not any(st1), (st0, st1)
     errs = {k: maxabs(got[k], ref[k]) for k in ref}
     print("chain vs launches, max-abs:", {k: f"{v:.2e}" for k, v in errs.items()})
@@ -135,13 +136,15 @@ def test_backward_chain_matches_per_step_backward(env):
         assert max(worst.values()) < 5e-3, worst
 
 
-def test_backward_consumes_chain_activations(env):
+@pytest.mark.parametrize("att", [SMA, LSA])
+def test_backward_consumes_chain_activations(env, att):
     """The hand-written BPTT reads what the persistent forward saved (gates, cells, DIN / DOUT rows, queries, selection
-    probabilities, alignments): gradients from a chain forward match gradients from a per-step forward."""
+    probabilities / cumulative weights, alignments): gradients from a chain forward (+ for SMA the persistent backward)
+    match gradients from the per-step path."""
     L, ops = env
     res = {}
     for chain in (False, True):
-        out, st, (W, P, dims, dp, mem, mems) = _run(env, SMA, 8, 21, 12, 10, chain=chain, training=True)
+        out, st, (W, P, dims, dp, mem, mems) = _run(env, att, 8, 21, 12, 10, chain=chain, training=True)
         assert not any(st)
         g = torch.Generator(device="cuda").manual_seed(3)
         dmel = torch.randn(8, 10, 80, device="cuda", generator=g)
