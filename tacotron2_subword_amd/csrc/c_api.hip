@@ -175,13 +175,14 @@ InferShadows infer_shadows(const Sizes& z, size_t base) {
 
 // Persistent chains: [status word | counters A | counters B | X of chain A | X of chain B | Q], each part 256-byte aligned.
 // Sized for the largest tiling chain_plan can choose at this batch size.
-struct ChainBufs { unsigned* err; unsigned* cnt_a; unsigned* cnt_b; unsigned char* xa; unsigned char* xb; float* q; size_t xa_bytes, xb_bytes, q_bytes; };
+struct ChainBufs { unsigned* err; unsigned* cnt_a; unsigned* cnt_b; unsigned char* xa; unsigned char* xb; unsigned char* xm; float* q; size_t xa_bytes, xb_bytes, q_bytes; };
+constexpr size_t kChainXmBytes = 16 * 1024;     // decode loop: mel fragments [2][8][1 KB]
 size_t chain_part_bytes(const Sizes& z, size_t* xa, size_t* xb, size_t* q) {
     const size_t MT = (z.B + 31) / 32;
-    *xa = (size_t)2 * z.NS * ((z.Ha + z.E) / 16) * MT * 1024;
+    *xa = (size_t)2 * z.NS * ((z.Ha + z.E + z.P) / 16) * MT * 1024;      // (+ the prenet segment of the decode loop)
     *xb = (size_t)2 * (z.Hd / 16) * MT * 1024;
     *q = (size_t)z.NS * MT * 32 * (z.Ha / 8) * z.A * sizeof(float);
-    return 256 + 2 * kChainCntBytes + *xa + *xb + *q;
+    return 256 + 2 * kChainCntBytes + *xa + *xb + kChainXmBytes + *q;
 }
 size_t chain_region_bytes(const Sizes& z) { size_t a, b, q; return (chain_part_bytes(z, &a, &b, &q) + 255) & ~(size_t)255; }
 ChainBufs chain_bufs(const Sizes& z, const t2_decoder_layout& L, float* ws) {
@@ -193,6 +194,7 @@ ChainBufs chain_bufs(const Sizes& z, const t2_decoder_layout& L, float* ws) {
     b.cnt_b = reinterpret_cast<unsigned*>(p); p += kChainCntBytes;
     b.xa = p; p += b.xa_bytes;
     b.xb = p; p += b.xb_bytes;
+    b.xm = p; p += kChainXmBytes;
     b.q = reinterpret_cast<float*>(p);
     return b;
 }
@@ -502,6 +504,49 @@ bool chain_b_desc(const Dec& c, ChainDesc* out) {
     chain_exchange_bytes(d, &xb, &qb);
     if (xb > b.xb_bytes) return false;
     d.X = b.xb; d.Q = nullptr; d.cnt = b.cnt_b; d.err = b.err + 1; d.q_bytes = 0;
+    *out = d;
+    return true;
+}
+
+// Persistent decode loop (chain.hip, dec mode): every phase of Decoder.inference's step inside one launch per step range
+bool chain_dec_desc(const Dec& c, const t2_decoder_weights& w, const t2_decoder_infer_args& a, ChainDesc* out) {
+    const Sizes& z = c.z; const t2_decoder_layout& L = c.L;
+    if (!c.use16 || z.NS != 2) return false;
+    if (c.d.attention_kind != T2_ATTN_SMA && c.d.attention_kind != T2_ATTN_LSA) return false;
+    ChainDesc d{};
+    d.dec = 1; d.P = z.P; d.M = z.M; d.Hd = z.Hd;
+    d.NS = z.NS; d.B = z.B; d.T = z.T; d.H = z.Ha; d.E = z.E; d.A = z.A; d.WD = z.WD; d.WO = z.WO;
+    d.kind = c.d.attention_kind == T2_ATTN_SMA ? CHAIN_SMA : CHAIN_LSA;
+    d.F = c.d.loc_filters; d.Kc = c.d.loc_kernel; d.max_pos = c.max_pos;
+    d.drop_p = 0.f; d.noise_std = 0.f; d.seed = c.seed;                 // inference runs in eval mode (inference.py:263)
+    for (int s = 0; s < z.NS; ++s) {
+        ChainStream& st = d.st[s];
+        const t2_attention_weights& aw = s ? w.attn_sub : w.attn;
+        const t2_lstm_weights& lw = s ? w.att_sub : w.att;
+        st.w16 = c.P16(c.I.wa[s]); st.ldw16 = c.I.Ka; st.wq = aw.wq;
+        st.pm = c.P(s ? L.pms : L.pm); st.memory = s ? c.memory_sub : c.memory; st.lengths = s ? c.len_sub : c.len;
+        st.Tin = s ? z.Tsub : z.Tin;
+        st.align = s ? c.align_sub : c.align; st.wcum = c.P(s ? L.wcums : L.wcum);
+        st.v = aw.v; st.loc_conv = aw.loc_conv; st.loc_dense = aw.loc_dense;
+        st.site_h = s ? T2_SITE_ATT_H_SUB : T2_SITE_ATT_H; st.site_c = s ? T2_SITE_ATT_C_SUB : T2_SITE_ATT_C;
+        st.site_noise = s ? T2_SITE_NOISE_SUB : T2_SITE_NOISE;
+        st.mask_value = mask_value_of(c.d, s);
+        d.bias1[s] = lw.b_ih; d.bias2[s] = lw.b_hh;
+        d.att_c[s] = c.P(s ? L.cas : L.ca);                              // (row 0 of the per-frame buffers: unused in decode)
+        d.pw1[s] = s ? w.prenet_sub_w1 : w.prenet_w1; d.pw2[s] = s ? w.prenet_sub_w2 : w.prenet_w2;
+        d.psite1[s] = s ? T2_SITE_PRENET1_SUB : T2_SITE_PRENET1; d.psite2[s] = s ? T2_SITE_PRENET2_SUB : T2_SITE_PRENET2;
+    }
+    d.wd16 = c.P16(c.I.wd); d.ldwd = c.I.Kd; d.dbias1 = w.dec.b_ih; d.dbias2 = w.dec.b_hh; d.dec_c = c.P(L.cd);
+    d.proj_w = w.proj_w; d.proj_b = w.proj_b; d.gate_w = w.gate_w; d.gate_b = w.gate_b;
+    d.mel_out = a.mel_out; d.ldmel = (long)z.T * z.M; d.gate_out = a.gate_out; d.ldgate = z.T;
+    d.thr = a.gate_threshold; d.stop_index = a.stop_index; d.done = a.done_count;
+    d.pdrop = c.prenet_dropout ? c.d.p_prenet_dropout : 0.f;
+    if (!chain_plan(d)) return false;
+    const ChainBufs b = chain_bufs(z, L, c.ws);
+    size_t xb = 0, qb = 0;
+    chain_exchange_bytes(d, &xb, &qb);
+    if (xb > b.xa_bytes || qb > b.q_bytes || (size_t)2 * (z.Hd / 16) * 1024 > b.xb_bytes) return false;
+    d.X = b.xa; d.Q = b.q; d.cnt = b.cnt_a; d.err = b.err; d.q_bytes = (unsigned)qb; d.XD = b.xb; d.XM = b.xm;
     *out = d;
     return true;
 }
@@ -928,7 +973,7 @@ int t2_decoder_forward(const t2_dims* dims_in, const t2_decoder_weights* w, cons
     const bool chain_a = g_chain && chain_a_desc(c, &ca), chain_b = g_chain && chain_b_desc(c, &cb);
     {   // status words always (0 = OK / not used); counters and the zero state of step -1 when a chain runs
         const ChainBufs bufs = chain_bufs(z, L, a->ws);
-        T2_CHECK_HIP(hipMemsetAsync(bufs.err, 0, (chain_a || chain_b) ? 256 + 2 * kChainCntBytes + bufs.xa_bytes + bufs.xb_bytes : 256, c.s));
+        T2_CHECK_HIP(hipMemsetAsync(bufs.err, 0, (chain_a || chain_b) ? 256 + 2 * kChainCntBytes + bufs.xa_bytes + bufs.xb_bytes + kChainXmBytes : 256, c.s));
     }
     Side* side = nullptr;
     const bool overlap = g_overlap && z.T >= 32 && !chain_a && !chain_b;
@@ -1280,12 +1325,28 @@ int t2_decoder_infer(const t2_dims* dims_in, const t2_decoder_weights* w, const 
     int steps = 0;
     StopPoll* pl = nullptr;
     T2_TRY(stop_poll_get(&pl));
-    T2_TRY(tail(0, false));                                          // prenet of the go frame (model.py:444-450)
+    ChainDesc cdec{};
+    const bool chain = g_chain && chain_dec_desc(c, *w, *a, &cdec);
+    if (chain) {                                                     // status, counters, zero state of step -1 (h, ctx, dec_h, go-frame prenet = 0)
+        const ChainBufs bufs = chain_bufs(z, L, a->ws);
+        T2_CHECK_HIP(hipMemsetAsync(bufs.err, 0, 256 + 2 * kChainCntBytes + bufs.xa_bytes + bufs.xb_bytes + kChainXmBytes, c.s));
+    } else {
+        const ChainBufs bufs = chain_bufs(z, L, a->ws);
+        T2_CHECK_HIP(hipMemsetAsync(bufs.err, 0, 256, c.s));
+        T2_TRY(tail(0, false));                                      // prenet of the go frame (model.py:444-450)
+    }
     for (int t = 0; t < T; ++t) {
-        T2_TRY(att_lstm_step(c, t));
-        T2_TRY(attention_step(c, t));
-        T2_TRY(dec_lstm_step(c, t));
-        T2_TRY(tail(t, true));                                       // mel_t, gate_t, stop rule, prenets of step t+1 (:470-471)
+        if (chain) {
+            if (t % poll == 0) {                                     // one persistent launch per polling interval
+                cdec.t0 = t; cdec.t1 = std::min(T, t + poll);
+                T2_TRY(chain_fwd(cdec, c.s));
+            }
+        } else {
+            T2_TRY(att_lstm_step(c, t));
+            T2_TRY(attention_step(c, t));
+            T2_TRY(dec_lstm_step(c, t));
+            T2_TRY(tail(t, true));                                   // mel_t, gate_t, stop rule, prenets of step t+1 (:470-471)
+        }
         steps = t + 1;
         if (steps % poll == 0 && steps < T) {
             // Stop rule without draining the queue: the counter is copied to pinned memory behind an event; the host reads

@@ -67,7 +67,7 @@ __host__ __device__ inline Geo geo_of(const ChainDesc& d, int UT, int RT) {
     Geo g;
     g.MT = (d.B + 31) / 32; g.NRG = (g.MT + RT - 1) / RT; g.NUG = d.H / (8 * UT);
     g.nL = d.NS * g.NUG * g.NRG; g.nA = d.kind == CHAIN_LSTM ? 0 : d.NS * d.B * d.CS;
-    g.KT = (d.H + (d.kind == CHAIN_LSTM ? 0 : d.E)) / 16;
+    g.KT = (d.H + (d.kind == CHAIN_LSTM ? 0 : d.E) + (d.dec ? d.P : 0)) / 16;
     g.xs_bytes = (unsigned)g.KT * g.MT * 1024u;
     return g;
 }
@@ -101,9 +101,10 @@ __host__ __device__ inline Lds lds_of(const ChainDesc& d, int UT, int RT, int Ti
     return m;
 }
 
-template <int UT, int RT, int KH, int KC, int KIND>
+template <int UT, int RT, int KH, int KC, int KIND, int KPN = 0>
 __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
     constexpr int NTILE = UT * RT, NSLOT = (NTILE + 1) / 2, HSP = UT * 8 + 4;
+    constexpr bool DEC = KPN > 0;                       // decode loop: prenet segment in the LSTM product + decoder LSTM, projections, prenets in the launch
     const Geo G = geo_of(d, UT, RT);
     const int wg = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hk = lane >> 5;
     const int B = d.B, H = d.H, A = d.A;
@@ -121,7 +122,10 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
     const int arg = ab_ / (32 * RT), arow = ab_ % (32 * RT);         // row group / local row of the A item
     const int EC = KIND == CHAIN_LSTM ? 0 : d.E / d.CS, c0 = part * EC;
     const int Tin = hasA ? AS.Tin : 4, Tp = (Tin + 3) & ~3;
-    const int Jp = hasA ? (as ? d.Jp[1] : d.Jp[0]) : 0, Jm = hasA ? (as ? d.Jm[1] : d.Jm[0]) : 0;
+    // decode loop: the few workgroups that also own a projection / prenet item keep THOSE weights in the LDS area of the
+    // attention operands (as ready-made MFMA B fragments) and read their attention rows from L2 instead
+    const bool prole = DEC && (wg < (d.M + 1 + 15) / 16 || (wg >= 64 && wg < 64 + d.NS * (d.P / 16)));
+    const int Jp = (hasA && !prole) ? (as ? d.Jp[1] : d.Jp[0]) : 0, Jm = (hasA && !prole) ? (as ? d.Jm[1] : d.Jm[0]) : 0;
     const Lds M = lds_of(d, UT, RT, d.lds_Tin, d.lds_Jp, d.lds_Jm);   // one carve for every workgroup (largest stream)
     unsigned* abortw = reinterpret_cast<unsigned*>(smem + M.ab);
     float* vL = smem + M.v; float* apL = smem + M.ap; float* cumL = smem + M.cum; float* qL = smem + M.q;
@@ -150,15 +154,15 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
     if (tid == 0) *abortw = 0;
 
     // ---------------------------------------------------------------- L setup: weight slice -> registers (once)
-    bf16x8 W[UT][KH + KC];
+    bf16x8 W[UT][KH + KC + KPN];
     float wqf[UT * 4];
     float cst[NSLOT];
     if (hasL) {
 #pragma unroll
         for (int ut = 0; ut < UT; ++ut)
 #pragma unroll
-            for (int i = 0; i < KH + KC; ++i) {
-                const int kt = i < KH ? wave * KH + i : H / 16 + wave * KC + (i - KH);
+            for (int i = 0; i < KH + KC + KPN; ++i) {
+                const int kt = i < KH ? wave * KH + i : i < KH + KC ? H / 16 + wave * KC + (i - KH) : (H + d.E) / 16 + wave * KPN + (i - KH - KC);
                 const long row = (long)(r >> 3) * H + u0 + ut * 8 + (r & 7);
                 W[ut][i] = *reinterpret_cast<const bf16x8*>(LS.w16 + row * LS.ldw16 + kt * 16 + 8 * hk);
             }
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             float c = 0.f;
             if (tp < NTILE && d.t0 > 0) {
                 const int b = row0 + (tp / UT) * 32 + ((tid & 255) >> 3), u = u0 + (tp % UT) * 8 + (tid & 7);
-                if (b < B) c = LS.c_out[((long)(d.t0 - 1) * B + b) * H + u];
+                if (b < B) c = DEC ? d.att_c[ls][(long)b * H + u] : LS.c_out[((long)(d.t0 - 1) * B + b) * H + u];
             }
             cst[sl] = c;
         }
@@ -221,7 +225,9 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             const int tp = 2 * sl + (tid >> 8);
             const int b = min(row0 + (tp / UT) * 32 + ((tid & 255) >> 3), B - 1), u = u0 + (tp % UT) * 8 + (tid & 7);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pre_next[sl][g] = (hasL && tp < NTILE) ? LS.pre[((long)t * B + b) * 4 * H + g * H + u] : 0.f;
+            for (int g = 0; g < 4; ++g)
+                pre_next[sl][g] = !(hasL && tp < NTILE) ? 0.f : DEC ? d.bias1[ls][g * H + u] + d.bias2[ls][g * H + u]      // (constant over the steps)
+                                                                    : LS.pre[((long)t * B + b) * 4 * H + g * H + u];
         }
     };
     load_pre(d.t0, tid);
@@ -267,10 +273,81 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 acc[ut] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, hf[i]), W[ut][i], acc[ut], 0, 0, 0);
     };
 
+
+    // ---------------------------------------------------------------- decode loop: decoder LSTM (D), projections (P1), prenets (P2)
+    // D item: 4 hidden units (16 gate columns) x all rows, K = 2(H+E) + Hd split over the 8 waves (512 each: one source segment
+    // per wave), v_mfma_f32_16x16x32_bf16; P1 item: 16 of the n_mel + 1 (gate) output columns, K = Hd + 2E; P2 item: stream s,
+    // 16 of the P second-layer columns (it recomputes the whole first layer).  Weights of all three stay in registers.
+    constexpr int DU = 4, DNW = 16;                             // D: units per item, k blocks of 32 per wave
+    const int Hd = DEC ? d.Hd : 16, Pn = DEC ? d.P : 16, Mm = DEC ? d.M : 16, Ee = d.E;
+    const bool hasD = DEC && wg < Hd / DU, hasP1 = DEC && wg < (Mm + 1 + 15) / 16, hasP2 = DEC && wg >= 64 && wg < 64 + d.NS * (Pn / 16);
+    const int du0 = wg * DU, p2s = hasP2 ? (wg - 64) / (Pn / 16) : 0, p2c = hasP2 ? (wg - 64) % (Pn / 16) : 0;
+    bf16x8 WD[DEC ? DNW : 1];
+    bf16x8* wfragL = reinterpret_cast<bf16x8*>(smem + M.pm);      // P1: [wave][8 blocks][lane]; P2: W1 [wave][2][3][lane] then W2 [wave][lane]
+    float dcst = 0.f, dbias[4] = {0.f, 0.f, 0.f, 0.f};
+    auto cvt8 = [&](const float* p, int n_valid) {              // 8 consecutive floats -> bf16x8, zero past n_valid
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)(j < n_valid ? p[j] : 0.f);
+        return o;
+    };
+    if (DEC) {
+        const int j16 = lane & 15, kq = lane >> 4;
+        if (hasD) {
+#pragma unroll
+            for (int i = 0; i < DNW; ++i)
+                WD[i] = *reinterpret_cast<const bf16x8*>(d.wd16 + (long)((j16 >> 2) * Hd + du0 + (j16 & 3)) * d.ldwd + wave * (DNW * 32) + i * 32 + 8 * kq);
+            if (tid < 32 * DU) {
+                const int u = du0 + (tid & 3);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) dbias[g] = d.dbias1[g * Hd + u] + d.dbias2[g * Hd + u];
+                const int b = tid >> 2;
+                if (d.t0 > 0 && b < B) dcst = d.dec_c[(long)b * Hd + u];
+            }
+        }
+        if (hasP1) {
+            const int col = wg * 16 + j16, WO = Hd + d.NS * Ee;
+            const float* wr = col < Mm ? d.proj_w + (long)col * WO : d.gate_w;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wfragL[(wave * 8 + i) * 64 + lane] = cvt8(wr + wave * 256 + i * 32 + 8 * kq, col <= Mm ? 8 : 0);
+        }
+        if (hasP2) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int k = i * 32 + 8 * kq;
+                    wfragL[((wave * 2 + c) * 3 + i) * 64 + lane] = cvt8(d.pw1[p2s] + (long)((wave * 2 + c) * 16 + j16) * Mm + min(k, Mm - 8), k < Mm ? 8 : 0);
+                }
+            wfragL[(NWV * 6 + wave) * 64 + lane] = cvt8(d.pw2[p2s] + (long)(p2c * 16 + j16) * Pn + wave * 32 + 8 * kq, 8);
+        }
+    }
+    auto rsD = __builtin_amdgcn_make_buffer_rsrc(d.XD, 0, DEC ? 2 * (Hd / 16) * 1024 : 0, 0x00020000);
+    auto rsM = __builtin_amdgcn_make_buffer_rsrc(d.XM, 0, DEC ? 2 * 8 * 1024 : 0, 0x00020000);
+    float* partDL = smem + M.scratch;                           // [NWV][32][20]  K-split partials of a 16-column item
+    float* stgL = smem + M.scratch + NWV * 32 * 20;            // [32][20] staging of a finished 32 x 16 tile
+    __bf16* h1L = reinterpret_cast<__bf16*>(smem + M.scratch + NWV * 32 * 20 + 32 * 20);   // P2: first-layer output [32][Pn + 8] bf16
+    // fragment address of the 16x16x32 A operand (rows i + 16*rt16, 8 k at kofs..) inside a fragment-ordered buffer
+    auto frag16 = [&](int lane, int kofs, int rt16) {         // (lane: the step's opaque copy, so that these offsets are not hoisted)
+        const int j16 = lane & 15, kq = lane >> 4, k = kofs + 8 * kq;
+        return (unsigned)((((k >> 4) * G.MT) * 64 + ((k >> 3) & 1) * 32 + j16 + 16 * rt16) * 16);
+    };
+
     float sv[NSLOT][7];
     // saved activations (backward pass) and module-level outputs: plain stores, always issued right AFTER the loads the
     // step needs next (vector-memory operations complete in order: a store in front of a load delays the load)
     auto store_L_saved = [&](int t, int tid) {
+        if (DEC) {                                              // inference keeps nothing but the state the next launch resumes from
+            if (t == d.t1 - 1) {
+#pragma unroll
+                for (int sl = 0; sl < NSLOT; ++sl) {
+                    const int tp = 2 * sl + (tid >> 8);
+                    const int b = row0 + (tp / UT) * 32 + ((tid & 255) >> 3), u = u0 + (tp % UT) * 8 + (tid & 7);
+                    if (tp < NTILE && b < B) d.att_c[ls][(long)b * H + u] = sv[sl][5];
+                }
+            }
+            return;
+        }
 #ifndef T2_CHAIN_NOSAVE
 #pragma unroll
         for (int sl = 0; sl < NSLOT; ++sl) {
@@ -289,6 +366,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
 #endif
     };
     auto store_A_saved = [&](int t, int tid) {                        // context of step t (still in csL)
+        if (DEC) return;
 #ifndef T2_CHAIN_NOSAVE
         const long rb = (long)t * B + ab_;
         for (int c = tid; c < EC; c += NTH) {
@@ -330,7 +408,11 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             T2_CSTAMP(0);
             if (EARLY) issue_h(t - 1);
             if (KC > 0) {
-                if (wave == 0 && !poll_counter(cntC_L, ep * nA_per_step, d.err, 2u) && lane == 0) *abortw = 1;
+                if (wave == 0) {
+                    bool ok = poll_counter(cntC_L, ep * nA_per_step, d.err, 2u);
+                    if (ok && DEC) ok = poll_counter(d.cnt + (size_t)(10 + ls) * CNT_STRIDE, ep * (unsigned)(d.P / 16), d.err, 11u);   // prenet output of this step
+                    if (!ok && lane == 0) *abortw = 1;
+                }
                 __syncthreads();
                 if (*abortw) return;
             }
@@ -341,6 +423,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             for (int rt = 0; rt < RT; ++rt) {
                 if (!EARLY) { zero_acc(); gemm_part(t - 1, rt, wave * KH, 0, std::integral_constant<int, KH>{}); }
                 if (KC > 0) gemm_part(t - 1, rt, H / 16 + wave * KC, KH, std::integral_constant<int, KC>{});
+                if (DEC) gemm_part(t - 1, rt, (H + d.E) / 16 + wave * KPN, KH + KC, std::integral_constant<int, KPN>{});
                 T2_CSTAMP(14);
 #pragma unroll
                 for (int ut = 0; ut < UT; ++ut) {
@@ -421,7 +504,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             // saved activations: issued here, in the slack before the next poll is answered (issuing scattered stores costs
             // the wave hundreds of cycles; behind the next phase's loads they sat on the critical path: measured +1.2 us/step)
             store_L_saved(t, tv);
-            if (!hasA && more) load_pre(t + 1, tv);
+            if (!DEC && !hasA && more) load_pre(t + 1, tv);
         }
         // ======================================================================================= A(t)
         if (hasA) {
@@ -458,7 +541,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 *reinterpret_cast<f32x4*>(redL + pg * A + a4) = accq;
                 // the next step's pre-activations (cold HBM rows): requested here, where this wave needs nothing from
                 // memory until the context is published (vector-memory operations complete in order)
-                if (more) load_pre(t + 1, tid);
+                if (!DEC && more) load_pre(t + 1, tid);
             }
             __syncthreads();
             if (tid < A) {
@@ -466,7 +549,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) sum += redL[k * A + tid];
                 qL[tid] = sum;
-                if (part == 0) AS.qs[((long)t * B + ab_) * A + tid] = sum;
+                if (!DEC && part == 0) AS.qs[((long)t * B + ab_) * A + tid] = sum;
             }
             if (KIND == CHAIN_LSA) {
                 // ---- location features of [w_{t-1}; cum_{t-1}] (attention.py:7-23): conv (2 -> F channels, Kc taps, zero padded),
@@ -584,7 +667,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                     if (d.noise_std > 0.f) ev += d.noise_std * rng_normal(kn, (uint32_t)(((long)t * B + ab_) * Tin + j));
                     const float p = fast_sigmoid(ev);
                     eL[j] = p;
-                    if (part == 0) AS.psel[((long)ab_ * d.T + t) * Tin + j] = p;
+                    if (!DEC && part == 0) AS.psel[((long)ab_ * d.T + t) * Tin + j] = p;
                 }
                 __syncthreads();
                 for (int j = tid; j < Tin; j += NTH) {
@@ -678,6 +761,209 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             T2_CSTAMP(12);
             store_A_saved(t, tid);
         }
+        if (DEC) {
+            const int tid = tv, lane = tid & 63, wave = tid >> 6, r = lane & 31, hk = lane >> 5;     // rebuilt from the opaque copy
+            const int j16 = lane & 15, kq = lane >> 4;
+            const unsigned xcur = (unsigned)((t & 1) * d.NS) * G.xs_bytes;           // h_t / ctx_t of both streams
+            unsigned* cntD = d.cnt + (size_t)8 * CNT_STRIDE;
+            unsigned* cntM = d.cnt + (size_t)9 * CNT_STRIDE;
+            // =================================================================================== D(t): decoder LSTM (model.py:371-373)
+            if (hasD) {
+                if (wave == 0) {             // h_t and ctx_t of both streams, dec_h_{t-1}: five counters, one request
+                    const unsigned* cp = lane == 0 ? d.cnt + (size_t)0 * CNT_STRIDE : lane == 1 ? d.cnt + (size_t)1 * CNT_STRIDE
+                                       : lane == 2 ? d.cnt + (size_t)2 * CNT_STRIDE : lane == 3 ? d.cnt + (size_t)3 * CNT_STRIDE : cntD;
+                    const unsigned want = (lane & 1) == 0 && lane < 4 ? (ep + 1) * (unsigned)G.NUG : lane < 4 ? (ep + 1) * (unsigned)(B * d.CS)
+                                        : ep * (unsigned)(Hd / DU);
+                    const unsigned long long t0c = __builtin_amdgcn_s_memrealtime();
+                    bool ok = true;
+                    for (;;) {
+                        const unsigned v = __hip_atomic_load(cp, T2_RLX_AGENT);
+                        if (__all(v >= want)) break;
+                        if (__builtin_amdgcn_s_memrealtime() - t0c > SPIN_TICKS) { ok = false; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (!ok && lane == 0) { atomicMax(d.err, 12u); *abortw = 1; }
+                }
+                __syncthreads();
+                if (*abortw) return;
+                // K order of [W_ih | W_hh]: [h0 (H) | ctx0 (E) | h1 (H) | ctx1 (E) | dec_h (Hd)]; wave w covers k in [512 w, 512 w + 512)
+                const int kg = wave * (DNW * 32);
+                const int seg0 = H + Ee, seg1 = 2 * (H + Ee);
+                const bool from_d = kg >= seg1;
+                const int st = kg < seg0 ? 0 : 1;
+                const int lk = from_d ? kg - seg1 : kg - st * seg0;                  // k inside the source buffer ([h | ctx] of a stream)
+                const unsigned base = from_d ? (unsigned)(((t + 1) & 1) * (Hd / 16) * 1024) : xcur + (unsigned)st * G.xs_bytes;
+                f32x4 accd[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int i0 = 0; i0 < DNW; i0 += 4) {
+                    u32x4 af[4][2];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+                            af[i][m] = from_d ? __builtin_amdgcn_raw_buffer_load_b128(rsD, base + frag16(lane, lk + (i0 + i) * 32, m), 0, SC1)
+                                              : __builtin_amdgcn_raw_buffer_load_b128(rsX, base + frag16(lane, lk + (i0 + i) * 32, m), 0, SC1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+                            accd[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i][m]), WD[i0 + i], accd[m], 0, 0, 0);
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) partDL[(wave * 32 + m * 16 + kq * 4 + e) * 20 + j16] = accd[m][e];
+                __syncthreads();
+                if (tid < 32 * DU) {
+                    const int row = tid >> 2, uu = tid & 3;
+                    float g4[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int w = 0; w < NWV; ++w) sum += partDL[(w * 32 + row) * 20 + g * 4 + uu];
+                        g4[g] = sum + dbias[g];
+                    }
+                    const float ig = fast_sigmoid(g4[0]), fg = fast_sigmoid(g4[1]), gg = fast_tanh(g4[2]), og = fast_sigmoid(g4[3]);
+                    const float cn = fg * dcst + ig * gg;
+                    dcst = cn;                                                       // (inference: no dropout on the carried state)
+                    stgL[row * 20 + uu] = row < B ? og * fast_tanh(cn) : 0.f;
+                    if (t == d.t1 - 1 && row < B) d.dec_c[(long)row * Hd + du0 + uu] = cn;
+                }
+                __syncthreads();
+                if (tid < 32) {              // dec_h_t: 4 units of a row = 8 bytes of the row's fragment piece
+                    const f32x4 h4 = *reinterpret_cast<const f32x4*>(stgL + tid * 20);
+                    bf16x4 o; o[0] = (__bf16)h4[0]; o[1] = (__bf16)h4[1]; o[2] = (__bf16)h4[2]; o[3] = (__bf16)h4[3];
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsD,
+                        (unsigned)((t & 1) * (Hd / 16) * 1024) + (unsigned)((((du0 >> 4) * 64) + ((du0 >> 3) & 1) * 32 + tid) * 16 + ((du0 & 7) >> 2) * 8), 0, SC1);
+                }
+                publish(cntD);
+            }
+            // =================================================================================== P1(t): mel / gate projections + stop rule (model.py:382-388, 461-480)
+            if (hasP1) {
+                if (wave == 0 && !poll_counter(cntD, (ep + 1) * (unsigned)(Hd / DU), d.err, 13u) && lane == 0) *abortw = 1;
+                __syncthreads();
+                if (*abortw) return;
+                // K order of the projections: [dec_h (Hd) | ctx0 (E) | ctx1 (E)]; wave w covers k in [256 w, 256 w + 256)
+                const int kg = wave * 256;
+                const bool from_d = kg < Hd;
+                const int st = kg < Hd + Ee ? 0 : 1;
+                const int lk = from_d ? kg : H + (kg - Hd - st * Ee);                // ctx sits behind h in a stream's fragments
+                const unsigned base = from_d ? (unsigned)((t & 1) * (Hd / 16) * 1024) : xcur + (unsigned)st * G.xs_bytes;
+                f32x4 accp[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int i0 = 0; i0 < 8; i0 += 4) {
+                    u32x4 af[4][2];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+                            af[i][m] = from_d ? __builtin_amdgcn_raw_buffer_load_b128(rsD, base + frag16(lane, lk + (i0 + i) * 32, m), 0, SC1)
+                                              : __builtin_amdgcn_raw_buffer_load_b128(rsX, base + frag16(lane, lk + (i0 + i) * 32, m), 0, SC1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const bf16x8 wb = wfragL[(wave * 8 + i0 + i) * 64 + lane];
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+                            accp[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i][m]), wb, accp[m], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) partDL[(wave * 32 + m * 16 + kq * 4 + e) * 20 + j16] = accp[m][e];
+                __syncthreads();
+                {
+                    const int row = tid >> 4, col = wg * 16 + (tid & 15);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NWV; ++w) sum += partDL[(w * 32 + row) * 20 + (tid & 15)];
+                    float val = 0.f;
+                    if (col < Mm) {
+                        val = sum + d.proj_b[col];
+                        if (row < B) d.mel_out[(long)row * d.ldmel + (long)t * Mm + col] = val;
+                    } else if (col == Mm && row < B) {
+                        const float gt = sum + d.gate_b[0];
+                        d.gate_out[(long)row * d.ldgate + t] = gt;
+                        if (d.stop_index && d.stop_index[row] < 0 && 1.0f / (1.0f + expf(-gt)) > d.thr) { d.stop_index[row] = t; atomicAdd(d.done, 1); }
+                    }
+                    stgL[row * 20 + (tid & 15)] = (col < Mm && row < B) ? val : 0.f;            // next step's prenet input (teacher = own output)
+                }
+                __syncthreads();
+                if (wave == 0) {             // mel_t columns [16 wg, +16) as one bf16 fragment (k tile wg of the prenets' K)
+                    const float* hp = stgL + r * 20 + hk * 8;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(hp), hi = *reinterpret_cast<const f32x4*>(hp + 4);
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { o[j] = (__bf16)lo[j]; o[4 + j] = (__bf16)hi[j]; }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsM, (unsigned)(((t & 1) * 8 + wg) * 1024 + lane * 16), 0, SC1);
+                }
+                publish(cntM);
+            }
+            // =================================================================================== P2(t): both prenet layers of frame t+1 (model.py:13-24, 470-471)
+            if (hasP2 && t + 1 < d.T) {
+                if (wave == 0 && !poll_counter(cntM, (ep + 1) * (unsigned)((Mm + 1 + 15) / 16), d.err, 14u) && lane == 0) *abortw = 1;
+                __syncthreads();
+                if (*abortw) return;
+                const RngKey k1 = rng_key(d.seed, d.psite1[p2s]), k2 = rng_key(d.seed, d.psite2[p2s]);
+                const float pscale = d.pdrop > 0.f ? 1.0f / (1.0f - d.pdrop) : 1.0f;
+                const uint32_t ibase = (uint32_t)((long)(t + 1) * B * Pn);             // keep-bit index = (t+1)*B*P + b*P + n, as infer.hip
+                // layer 1: [32 x M] . W1^T -> 16 columns x 2 per wave; ReLU + dropout; bf16 rows in LDS
+                u32x4 mf[3][2];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        mf[i][m] = __builtin_amdgcn_raw_buffer_load_b128(rsM, (unsigned)((t & 1) * 8 * 1024) + frag16(lane, i * 32, m), 0, SC1);
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, mf[i][m]), wfragL[((wave * 2 + c) * 3 + i) * 64 + lane], a1, 0, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int row = m * 16 + kq * 4 + e, n = (wave * 2 + c) * 16 + j16;
+                            float v = fmaxf(a1[e], 0.f);
+                            if (d.pdrop > 0.f) v = rng_keep(k1, ibase + (uint32_t)(row * Pn + n), d.pdrop) ? v * pscale : 0.f;
+                            h1L[row * (Pn + 8) + n] = (__bf16)v;
+                        }
+                    }
+                __syncthreads();
+                // layer 2: this item's 16 columns, wave w takes k block w of the P inputs
+                f32x4 a2[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const bf16x8 hv = *reinterpret_cast<const bf16x8*>(h1L + (m * 16 + j16) * (Pn + 8) + wave * 32 + 8 * kq);
+                    a2[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hv, wfragL[(NWV * 6 + wave) * 64 + lane], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) partDL[(wave * 32 + m * 16 + kq * 4 + e) * 20 + j16] = a2[m][e];
+                }
+                __syncthreads();
+                {
+                    const int row = tid >> 4, n = p2c * 16 + (tid & 15);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int w = 0; w < Pn / 32; ++w) sum += partDL[(w * 32 + row) * 20 + (tid & 15)];
+                    float v = fmaxf(sum, 0.f);
+                    if (d.pdrop > 0.f) v = rng_keep(k2, ibase + (uint32_t)(row * Pn + n), d.pdrop) ? v * pscale : 0.f;
+                    stgL[row * 20 + (tid & 15)] = row < B ? v : 0.f;
+                }
+                __syncthreads();
+                if (wave == 0) {             // p2(t+1) columns [16 p2c, +16): one fragment behind h and ctx in the stream's exchange buffer
+                    const float* hp = stgL + r * 20 + hk * 8;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(hp), hi = *reinterpret_cast<const f32x4*>(hp + 4);
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { o[j] = (__bf16)lo[j]; o[4 + j] = (__bf16)hi[j]; }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsX,
+                        xcur + (unsigned)p2s * G.xs_bytes + (unsigned)((((H + Ee) / 16 + p2c) * G.MT) * 1024 + lane * 16), 0, SC1);
+                }
+                publish(d.cnt + (size_t)(10 + p2s) * CNT_STRIDE);
+            }
+        }
     }
 #ifdef T2_STAMPS
     if (tid == 0 && (KIND != CHAIN_LSTM) == (T2_STAMPS != 2))     // -DT2_STAMPS=1: the attention chain, =2: the decoder-LSTM chain
@@ -710,6 +996,7 @@ bool chain_plan(ChainDesc& d) {
     if (d.kind != CHAIN_LSTM && (d.E != 512 || d.A != 128 || d.NS < 1 || d.NS > 2)) return false;
     if (d.kind == CHAIN_LSA && (d.F + 1 > 64 || d.A % 32 != 0)) return false;
     const int MT = (d.B + 31) / 32;
+    if (d.dec && (MT != 1 || d.NS != 2 || d.kind == CHAIN_LSTM || d.P != 256 || d.Hd != 1024 || d.M + 1 > 96 || d.M % 8 != 0)) return false;
     if (d.kind == CHAIN_LSTM) { d.UT = 1; d.RT = MT <= 2 ? MT : 2; d.CS = 1; d.NS = 1; }
     else {
         d.RT = MT <= 2 ? 1 : 2;
@@ -733,6 +1020,7 @@ bool chain_plan(ChainDesc& d) {
         d.lds_Jm = std::min(tmax, left / (EC / 2)) & ~1;
         for (int s = 0; s < d.NS; ++s) { d.Jp[s] = std::min(d.st[s].Tin, d.lds_Jp); d.Jm[s] = std::min(d.st[s].Tin, d.lds_Jm); }
         if (getenv("T2_CHAIN_NO_RESIDENT")) { d.Jp[0] = d.Jp[1] = d.Jm[0] = d.Jm[1] = 0; }
+        if (d.dec && (size_t)d.lds_Jp * d.A * 4 + (size_t)d.lds_Jm * EC * 2 < 64 * 1024) return false;     // (projection / prenet fragments live there)
     }
     return true;
 }
@@ -744,15 +1032,15 @@ size_t chain_exchange_bytes(const ChainDesc& d, size_t* x_bytes, size_t* q_bytes
     return *x_bytes + *q_bytes;
 }
 
-template <int UT, int RT, int KC, int KIND>
+template <int UT, int RT, int KC, int KIND, int KPN = 0>
 static int chain_launch(const ChainDesc& d, hipStream_t s) {
     const Lds m = lds_of(d, UT, RT, d.lds_Tin, d.lds_Jp, d.lds_Jm);
     const size_t smem = (size_t)m.total * sizeof(float);
-    auto kernel = chain_fwd_kernel<UT, RT, 8, KC, KIND>;
+    auto kernel = chain_fwd_kernel<UT, RT, 8, KC, KIND, KPN>;
     T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const Geo g = geo_of(d, UT, RT);
-    const int grid = std::max(g.nL, g.nA);
-    T2_CHECK_HIP(hipMemsetAsync(d.cnt, 0, (size_t)d.NS * g.NRG * 2 * CNT_STRIDE * sizeof(unsigned), s));
+    const int grid = KPN > 0 ? 256 : std::max(g.nL, g.nA);
+    T2_CHECK_HIP(hipMemsetAsync(d.cnt, 0, KPN > 0 ? kChainCntBytes : (size_t)d.NS * g.NRG * 2 * CNT_STRIDE * sizeof(unsigned), s));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(NTH), smem, s, d);
     T2_LAUNCH_CHECK();
     return 0;
@@ -766,6 +1054,10 @@ int chain_fwd(const ChainDesc& d, hipStream_t s) {
         return chain_launch<1, 2, 0, CHAIN_LSTM>(d, s);
     }
     T2_REQUIRE(d.kind == CHAIN_SMA || d.kind == CHAIN_LSA, "chain_fwd: attention kind %d not covered", d.kind);
+    if (d.dec) {
+        T2_REQUIRE(d.UT == 1 && d.RT == 1 && d.XD && d.XM, "chain_fwd: decode loop needs one row tile and its exchange buffers");
+        return d.kind == CHAIN_LSA ? chain_launch<1, 1, 4, CHAIN_LSA, 2>(d, s) : chain_launch<1, 1, 4, CHAIN_SMA, 2>(d, s);
+    }
     if (d.kind == CHAIN_LSA) {
         if (d.UT == 1 && d.RT == 1) return chain_launch<1, 1, 4, CHAIN_LSA>(d, s);
         if (d.UT == 2 && d.RT == 1) return chain_launch<2, 1, 4, CHAIN_LSA>(d, s);

@@ -211,6 +211,19 @@ struct ChainDesc {
     float drop_p, noise_std; uint64_t seed;
     unsigned char* X; float* Q; unsigned* cnt; unsigned* err; unsigned q_bytes;   // exchange buffers (chain_exchange_bytes)
     int UT, RT, CS;                                // tiling chosen by chain_plan
+    // decode loop (dec = 1; Decoder.inference, model.py:430-492): whole-cell shadows [W_hh | W_ih[:,P:] | W_ih[:,:P]] in st[].w16,
+    // biases instead of hoisted pre-activations, and the decoder LSTM, the projections + stop rule and both prenets inside the launch
+    int dec, P, M, Hd;
+    const float* bias1[2]; const float* bias2[2];  // attention-LSTM biases [4H]
+    float* att_c[2];                               // [B][H] attention cell states carried between launches
+    const __bf16* wd16; long ldwd;                 // decoder-LSTM shadow [4Hd][WD + Hd] = [W_ih | W_hh]
+    const float* dbias1; const float* dbias2; float* dec_c;   // [4Hd] x2, [B][Hd] cell state between launches
+    const float* proj_w; const float* proj_b; const float* gate_w; const float* gate_b;   // [M][WO], [M], [WO], [1]
+    const float* pw1[2]; const float* pw2[2];      // prenet weights per stream [P][M], [P][P]
+    float* mel_out; long ldmel; float* gate_out; long ldgate;   // mel_out[b*ldmel + t*M + m], gate_out[b*ldgate + t]
+    float thr; int32_t* stop_index; int32_t* done;
+    float pdrop; uint32_t psite1[2], psite2[2];
+    unsigned char* XD; unsigned char* XM;          // exchange: dec_h fragments [2][Hd/16][1 KB], mel fragments [2][6][1 KB]
     int lds_Tin, lds_Jp, lds_Jm; int Jp[2], Jm[2]; // LDS residency: processed-memory / memory rows kept on chip
 };
 bool chain_plan(ChainDesc& d);                     // fills UT/RT/CS and the residency fields; false = shape not covered
