@@ -224,7 +224,10 @@ int t2_decoder_backward(const t2_dims* dims, const t2_decoder_weights* w, const 
  * memory behind an event and the host reads the copy made two polls earlier, so it only blocks when it is more than
  * 2*poll_every steps ahead of the GPU (the queue never drains); the loop therefore runs up to 3*poll_every steps past
  * the last stop.  Returns the number of steps run in *steps_run_host; frames after an item's stop index are
- * computed-but-meaningless. */
+ * computed-but-meaningless.  poll_every <= 0: 16 steps, or 32 with the persistent kernels.
+ * bf16 mode, default dims, B <= 32, SMA / LSA, t2_set_chain on: each polling interval is ONE persistent launch
+ * (csrc/chain.hip, decode mode) running the whole step — attention LSTMs, attention, decoder LSTM, projections + stop
+ * rule, both prenets — with every recurrent weight resident in registers; status word 0 of t2_decoder_layout.chain. */
 typedef struct t2_decoder_infer_args {
     int B, Tin, Tsub, max_steps, poll_every;
     float gate_threshold;

@@ -21,6 +21,7 @@ ap.add_argument("--T", type=int, default=400)
 ap.add_argument("--Tin", type=int, default=100)
 ap.add_argument("--Tsub", type=int, default=60)
 ap.add_argument("--att", default="sma")
+ap.add_argument("--decode", type=int, default=0, help="decoder steps of an inference() run instead of the teacher-forced pass")
 a = ap.parse_args()
 L.set_precision("bf16")
 hp = hp_for(SMA if a.att == "sma" else LSA)
@@ -36,9 +37,15 @@ bl = torch.full((a.B,), a.Tsub, device="cuda")
 lib = L.lib()
 NAMES = ["L wait h", "L h-part GEMM", "L wait ctx", "L reduce + gates", "L h/q stores", "L publish", "A (idle->start)", "A wait h",
          "A query sum", "A energies", "A recurrence", "A context", "A publish", "A saved stores", "L ctx loads + MFMA issue", "L saved stores + pre loads"]
+if a.decode:
+    NAMES[1], NAMES[6], NAMES[13] = "D wait h / ctx / dec_h", "D loads + MFMA + gates", "(A publish -> D start)"
 for it in range(3):
     lib.t2_debug_clear_chain_stamps()
-    dp = ops.decoder_forward(W, dims, mem, mems, tl, bl, mels, training=True, prenet_dropout=True, seed=it)
+    if a.decode:
+        a.T = a.decode
+        dp, n, stop = ops.decoder_infer(W, dims, mem, mems, max_steps=a.decode, gate_threshold=2.0, prenet_dropout=True, seed=it)
+    else:
+        dp = ops.decoder_forward(W, dims, mem, mems, tl, bl, mels, training=True, prenet_dropout=True, seed=it)
     torch.cuda.synchronize()
 buf = (C.c_ulonglong * (256 * 16))()
 lib.t2_debug_read_chain_stamps(buf, 256 * 16)

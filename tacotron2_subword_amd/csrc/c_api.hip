@@ -1274,7 +1274,7 @@ int t2_decoder_infer(const t2_dims* dims_in, const t2_decoder_weights* w, const 
     layout_of(*dims, c.z, &c.L);
     const Sizes& z = c.z; const t2_decoder_layout& L = c.L;
     const int T = z.T;
-    const int poll = a->poll_every > 0 ? a->poll_every : 16;
+    int poll = a->poll_every > 0 ? a->poll_every : 16;
 
     hipLaunchKernelGGL(init_stop_kernel, dim3((z.B + 63) / 64), dim3(64), 0, c.s, a->stop_index, a->done_count, z.B);
     T2_LAUNCH_CHECK();
@@ -1327,6 +1327,7 @@ int t2_decoder_infer(const t2_dims* dims_in, const t2_decoder_weights* w, const 
     T2_TRY(stop_poll_get(&pl));
     ChainDesc cdec{};
     const bool chain = g_chain && chain_dec_desc(c, *w, *a, &cdec);
+    if (chain && a->poll_every <= 0) poll = 32;                      // one persistent launch per polling interval: 32 steps amortise its start-up
     if (chain) {                                                     // status, counters, zero state of step -1 (h, ctx, dec_h, go-frame prenet = 0)
         const ChainBufs bufs = chain_bufs(z, L, a->ws);
         T2_CHECK_HIP(hipMemsetAsync(bufs.err, 0, 256 + 2 * kChainCntBytes + bufs.xa_bytes + bufs.xb_bytes + kChainXmBytes, c.s));

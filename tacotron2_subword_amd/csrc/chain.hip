@@ -124,7 +124,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
     const int Tin = hasA ? AS.Tin : 4, Tp = (Tin + 3) & ~3;
     // decode loop: the few workgroups that also own a projection / prenet item keep THOSE weights in the LDS area of the
     // attention operands (as ready-made MFMA B fragments) and read their attention rows from L2 instead
-    const bool prole = DEC && (wg < (d.M + 1 + 15) / 16 || (wg >= 64 && wg < 64 + d.NS * (d.P / 16)));
+    const bool prole = DEC && ((wg >= 128 && wg < 128 + (d.M + 1 + 15) / 16) || (wg >= 192 && wg < 192 + d.NS * (d.P / 16)));
     const int Jp = (hasA && !prole) ? (as ? d.Jp[1] : d.Jp[0]) : 0, Jm = (hasA && !prole) ? (as ? d.Jm[1] : d.Jm[0]) : 0;
     const Lds M = lds_of(d, UT, RT, d.lds_Tin, d.lds_Jp, d.lds_Jm);   // one carve for every workgroup (largest stream)
     unsigned* abortw = reinterpret_cast<unsigned*>(smem + M.ab);
@@ -280,8 +280,9 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
     // 16 of the P second-layer columns (it recomputes the whole first layer).  Weights of all three stay in registers.
     constexpr int DU = 4, DNW = 16;                             // D: units per item, k blocks of 32 per wave
     const int Hd = DEC ? d.Hd : 16, Pn = DEC ? d.P : 16, Mm = DEC ? d.M : 16, Ee = d.E;
-    const bool hasD = DEC && wg < Hd / DU, hasP1 = DEC && wg < (Mm + 1 + 15) / 16, hasP2 = DEC && wg >= 64 && wg < 64 + d.NS * (Pn / 16);
-    const int du0 = wg * DU, p2s = hasP2 ? (wg - 64) / (Pn / 16) : 0, p2c = hasP2 ? (wg - 64) % (Pn / 16) : 0;
+    // (projection and prenet items sit on workgroups 128.. / 192..: with the context in two column parts those own no attention item)
+    const bool hasD = DEC && wg < Hd / DU, hasP1 = DEC && wg >= 128 && wg < 128 + (Mm + 1 + 15) / 16, hasP2 = DEC && wg >= 192 && wg < 192 + d.NS * (Pn / 16);
+    const int du0 = wg * DU, p1g = wg - 128, p2s = hasP2 ? (wg - 192) / (Pn / 16) : 0, p2c = hasP2 ? (wg - 192) % (Pn / 16) : 0;
     bf16x8 WD[DEC ? DNW : 1];
     bf16x8* wfragL = reinterpret_cast<bf16x8*>(smem + M.pm);      // P1: [wave][8 blocks][lane]; P2: W1 [wave][2][3][lane] then W2 [wave][lane]
     float dcst = 0.f, dbias[4] = {0.f, 0.f, 0.f, 0.f};
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             }
         }
         if (hasP1) {
-            const int col = wg * 16 + j16, WO = Hd + d.NS * Ee;
+            const int col = p1g * 16 + j16, WO = Hd + d.NS * Ee;
             const float* wr = col < Mm ? d.proj_w + (long)col * WO : d.gate_w;
 #pragma unroll
             for (int i = 0; i < 8; ++i) wfragL[(wave * 8 + i) * 64 + lane] = cvt8(wr + wave * 256 + i * 32 + 8 * kq, col <= Mm ? 8 : 0);
@@ -768,6 +769,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             unsigned* cntD = d.cnt + (size_t)8 * CNT_STRIDE;
             unsigned* cntM = d.cnt + (size_t)9 * CNT_STRIDE;
             // =================================================================================== D(t): decoder LSTM (model.py:371-373)
+            T2_CSTAMP(13);
             if (hasD) {
                 if (wave == 0) {             // h_t and ctx_t of both streams, dec_h_{t-1}: five counters, one request
                     const unsigned* cp = lane == 0 ? d.cnt + (size_t)0 * CNT_STRIDE : lane == 1 ? d.cnt + (size_t)1 * CNT_STRIDE
@@ -786,6 +788,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 }
                 __syncthreads();
                 if (*abortw) return;
+                T2_CSTAMP(1);
                 // K order of [W_ih | W_hh]: [h0 (H) | ctx0 (E) | h1 (H) | ctx1 (E) | dec_h (Hd)]; wave w covers k in [512 w, 512 w + 512)
                 const int kg = wave * (DNW * 32);
                 const int seg0 = H + Ee, seg1 = 2 * (H + Ee);
@@ -838,6 +841,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsD,
                         (unsigned)((t & 1) * (Hd / 16) * 1024) + (unsigned)((((du0 >> 4) * 64) + ((du0 >> 3) & 1) * 32 + tid) * 16 + ((du0 & 7) >> 2) * 8), 0, SC1);
                 }
+                T2_CSTAMP(6);
                 publish(cntD);
             }
             // =================================================================================== P1(t): mel / gate projections + stop rule (model.py:382-388, 461-480)
@@ -875,7 +879,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                     for (int e = 0; e < 4; ++e) partDL[(wave * 32 + m * 16 + kq * 4 + e) * 20 + j16] = accp[m][e];
                 __syncthreads();
                 {
-                    const int row = tid >> 4, col = wg * 16 + (tid & 15);
+                    const int row = tid >> 4, col = p1g * 16 + (tid & 15);
                     float sum = 0.f;
 #pragma unroll
                     for (int w = 0; w < NWV; ++w) sum += partDL[(w * 32 + row) * 20 + (tid & 15)];
@@ -891,13 +895,13 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                     stgL[row * 20 + (tid & 15)] = (col < Mm && row < B) ? val : 0.f;            // next step's prenet input (teacher = own output)
                 }
                 __syncthreads();
-                if (wave == 0) {             // mel_t columns [16 wg, +16) as one bf16 fragment (k tile wg of the prenets' K)
+                if (wave == 0) {             // mel_t columns [16 p1g, +16) as one bf16 fragment (k tile p1g of the prenets' K)
                     const float* hp = stgL + r * 20 + hk * 8;
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(hp), hi = *reinterpret_cast<const f32x4*>(hp + 4);
                     bf16x8 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { o[j] = (__bf16)lo[j]; o[4 + j] = (__bf16)hi[j]; }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsM, (unsigned)(((t & 1) * 8 + wg) * 1024 + lane * 16), 0, SC1);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsM, (unsigned)(((t & 1) * 8 + p1g) * 1024 + lane * 16), 0, SC1);
                 }
                 publish(cntM);
             }
@@ -1001,7 +1005,7 @@ bool chain_plan(ChainDesc& d) {
     else {
         d.RT = MT <= 2 ? 1 : 2;
         d.UT = (d.NS * (d.H / 8) * ((MT + d.RT - 1) / d.RT) <= 256) ? 1 : 2;
-        d.CS = d.NS * d.B * 4 <= 256 ? 4 : d.NS * d.B * 2 <= 256 ? 2 : 1;
+        d.CS = (!d.dec && d.NS * d.B * 4 <= 256) ? 4 : d.NS * d.B * 2 <= 256 ? 2 : 1;      // (decode: 2, see the D / P items)
     }
     const Geo g = geo_of(d, d.UT, d.RT);
     if (g.nL > 256 || g.nA > 256) return false;

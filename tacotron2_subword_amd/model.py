@@ -294,6 +294,9 @@ class Decoder(nn.Module):
         flag = bool((stop >= 0).all())
         n = int(stop.max()) + 1 if flag else steps
         self.last_stop_index = stop
+        # decoder steps actually run / run past the last stop (the stop test is polled without draining the queue:
+        # include/t2amd.h t2_decoder_infer); what a latency-sensitive caller pays beyond the frames it gets
+        self.last_steps_run, self.last_overshoot = steps, steps - n
         mel = dp.mel[:, :n]
         return ((mel if channels_last else mel.transpose(1, 2)), dp.gate[:, :n].unsqueeze(-1), dp.align[:, :n], dp.align_sub[:, :n], flag)
 
