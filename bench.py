@@ -67,8 +67,13 @@ def decoder_step_bytes(hp, B, Tin, Tsub, wbytes=4):
     # chain_*: one persistent launch covers `steps` steps; its algorithmic bytes are the per-step figures above times the
     # steps (SURVEY.md section 8d counts what must move if nothing stays on chip between steps — the launch keeps the
     # weights in registers, so its HBM-side traffic is far below this figure; that is the point of it)
+    pw_att = 2 * B * Ha * 16 * 4          # pointwise BPTT of both attention LSTMs: gates, cells, dh sources in; dg (fp32 + bf16) out
+    pw_dec = B * Hd * 16 * 4
+    bwd_att = 2 * (4 * Ha * (E + Ha) + B * 4 * Ha) * wbytes + 2 * 8 * B * (E + Ha) * 4
+    bwd_dec = (4 * Hd * Hd + B * 4 * Hd) * wbytes + 8 * B * Hd * 4
     return dict(att_lstm_fwd=att, dec_lstm_fwd=dec, attention_fwd=attn, attention_bwd=2 * attn,
                 chain_a_fwd_per_step=att + attn, chain_b_fwd_per_step=dec,
+                chain_a_bwd_per_step=2 * attn + pw_att + bwd_att, chain_b_bwd_per_step=pw_dec + bwd_dec,
                 att_lstm_bwd_gemm=2 * (4 * Ha * (E + Ha) + B * 4 * Ha) * wbytes + 2 * 8 * B * (E + Ha) * 4,
                 dec_lstm_bwd_gemm=(4 * Hd * Hd + B * 4 * Hd) * wbytes + 8 * B * Hd * 4)
 
@@ -343,8 +348,8 @@ def main():
         torch.cuda.synchronize()
         bf = a.dtype == "bf16"
         fl, by = decoder_step_flops(hp, B, Tin, Tsub), decoder_step_bytes(hp, B, Tin, Tsub, 2 if bf else 4)
-        by["chain_a_fwd"] = by["chain_a_fwd_per_step"] * Tn          # one launch = all Tn steps
-        by["chain_b_fwd"] = by["chain_b_fwd_per_step"] * Tn
+        for k in ("chain_a_fwd", "chain_b_fwd", "chain_a_bwd", "chain_b_bwd"):
+            by[k] = by[k + "_per_step"] * Tn                         # one launch = all Tn steps
         kernels = {}
         for k, (ms, n) in prof.items():
             if n == 0:

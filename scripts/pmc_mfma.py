@@ -22,6 +22,10 @@ def main():
         t = kt[r["Dispatch_Id"]]
         m = re.search(r"(\w+)_kernel", r["Kernel_Name"])
         key = (m.group(1) if m else r["Kernel_Name"][:30]) + "_grid" + r["Grid_Size"]
+        targs = re.search(r"chain_fwd_kernel<([^>]*)>", r["Kernel_Name"])
+        if targs:                                        # persistent chains: one key per (attention kind, decode) instantiation
+            a = [x.strip() for x in targs.group(1).split(",")]
+            key = "chain_fwd_" + {"0": "lstm", "1": "sma", "2": "lsa"}.get(a[4], "x") + ("_decode" if len(a) > 5 and a[5] != "0" else "")
         agg.setdefault(key, []).append((float(r["Counter_Value"]), int(t["End_Timestamp"]) - int(t["Start_Timestamp"])))
     out = {}
     for k, v in agg.items():

@@ -22,13 +22,21 @@ def load(d, counter):
             if "bf16" in name and "bf16" not in short:
                 short += "_bf16"
             key = f"{short}_grid{r['Grid_Size']}"
+            if short == "chain_fwd":                     # persistent chains: one key per attention kind (5th template argument)
+                targs = re.search(r"chain_fwd_kernel<([^>]*)>", name)
+                kind = int(targs.group(1).split(",")[4]) if targs else -1
+                dec = targs and int(targs.group(1).split(",")[5]) > 0 if targs and len(targs.group(1).split(",")) > 5 else False
+                key = "chain_fwd_" + {0: "lstm", 1: "sma", 2: "lsa"}.get(kind, "x") + ("_decode" if dec else "")
+            elif short in ("chain_bwd_sma", "chain_bwd_lstm"):
+                key = short
             out.setdefault(key, []).append(float(r["Counter_Value"]))
     return out
 
 
 def main():
     fd, wd, dst = sys.argv[1:4]
-    keep = tuple(sys.argv[4].split(",")) if len(sys.argv) > 4 else ("lstm", "attention", "step", "proj", "prenet")
+    keep = tuple(sys.argv[4].split(",")) if len(sys.argv) > 4 else ("lstm", "attention", "step", "proj", "prenet", "chain")
+    steps = int(sys.argv[5]) if len(sys.argv) > 5 else 0      # steps one persistent chain launch covers in the profiled command
     F, W = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
     res = {}
     for k in sorted(set(F) | set(W)):
@@ -37,6 +45,9 @@ def main():
         f = statistics.median(F.get(k, [0.0])); w = statistics.median(W.get(k, [0.0]))
         res[k] = {"launches": len(F.get(k, [])), "FETCH_SIZE_KB_median": f, "WRITE_SIZE_KB_median": w,
                   "hbm_bytes_per_launch": (2 * f + w) * 1024}
+        if k.startswith("chain_") and steps:
+            res[k]["steps_per_launch"] = steps
+            res[k]["hbm_bytes_per_step"] = res[k]["hbm_bytes_per_launch"] / steps
     json.dump(res, open(dst, "w"), indent=1)
     for k, v in res.items():
         print(f"{k:50s} n={v['launches']:4d} fetch {v['FETCH_SIZE_KB_median']:10.1f} KB  write {v['WRITE_SIZE_KB_median']:9.1f} KB  hbm {v['hbm_bytes_per_launch'] / 1e6:8.2f} MB")

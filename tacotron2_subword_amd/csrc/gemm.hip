@@ -32,6 +32,7 @@ struct GemmK {
     GemmDesc d;
     int kchunks;    // K-chunks (of BK) per split
     int avec, bvec;  // 16-byte loads legal for A / B
+    int xcd_swizzle; // bf16-source kernel: XCD-aware tile order (tile count a multiple of 8)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -648,7 +649,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16src_kernel(GemmK g, con
     auto Bs = [&](int b) { return lds + 2 * (BM * PK16) + b * (BN * PK16); };
 
     const int split = blockIdx.z;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // Tile of this workgroup.  Workgroups are dealt round-robin over the 8 XCDs (linear id % 8) and every XCD has its own
+    // 4 MB L2: with the plain (x, y) -> (n, m) map each XCD sees every A row panel and one eighth of the B panels and
+    // re-fetches operands 5-6x (profiles/r01_pmc_gemm_traffic.json).  Remap so that an XCD works through a CONTIGUOUS
+    // run of tiles, ordered in groups of 8 tile rows (a group's tiles share 8 A panels and walk the B panels once).
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (g.xcd_swizzle) {
+        const int gx = gridDim.x, gy = gridDim.y, total = gx * gy;
+        const int lin = by * gx + bx;
+        const int pid = (lin & 7) * (total >> 3) + (lin >> 3);
+        constexpr int GM = 8;
+        const int per_group = GM * gx, group = pid / per_group, first_m = group * GM;
+        const int gsz = min(gy - first_m, GM);
+        by = first_m + (pid % per_group) % gsz;
+        bx = (pid % per_group) / gsz;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     const int kbeg = split * g.kchunks * BK, kend = min(d.K, kbeg + g.kchunks * BK);
     const __bf16* A = A16 + (long)m0 * lda;
     const __bf16* B = B16 + (long)n0 * ldb;
@@ -746,7 +762,10 @@ int launch_bf16src(const GemmK& g, const __bf16* pa, long lda, const __bf16* pb,
         T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16src_kernel<CONV_A, WM, WN, TM, TN, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_bf16src_kernel<CONV_A, WM, WN, TM, TN, PF>), dim3(g.d.N / BN, g.d.M / BM, splitk), dim3(64 * WM * WN), smem, s, g, pa, lda, pb, ldb);
+    GemmK gk = g;
+    static const int swz = getenv("T2_GEMM_XCD") ? atoi(getenv("T2_GEMM_XCD")) : 1;
+    gk.xcd_swizzle = swz && ((g.d.N / BN) * (g.d.M / BM)) % 8 == 0 && (g.d.M / BM) >= 8;
+    hipLaunchKernelGGL((gemm_bf16src_kernel<CONV_A, WM, WN, TM, TN, PF>), dim3(g.d.N / BN, g.d.M / BM, splitk), dim3(64 * WM * WN), smem, s, gk, pa, lda, pb, ldb);
     T2_LAUNCH_CHECK();
     return 0;
 }
