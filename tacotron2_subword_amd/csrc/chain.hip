@@ -771,25 +771,20 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             // =================================================================================== D(t): decoder LSTM (model.py:371-373)
             T2_CSTAMP(13);
             if (hasD) {
-                if (wave == 0) {             // h_t and ctx_t of both streams, dec_h_{t-1}: five counters, one request
-                    const unsigned* cp = lane == 0 ? d.cnt + (size_t)0 * CNT_STRIDE : lane == 1 ? d.cnt + (size_t)1 * CNT_STRIDE
-                                       : lane == 2 ? d.cnt + (size_t)2 * CNT_STRIDE : lane == 3 ? d.cnt + (size_t)3 * CNT_STRIDE : cntD;
-                    const unsigned want = (lane & 1) == 0 && lane < 4 ? (ep + 1) * (unsigned)G.NUG : lane < 4 ? (ep + 1) * (unsigned)(B * d.CS)
-                                        : ep * (unsigned)(Hd / DU);
-                    const unsigned long long t0c = __builtin_amdgcn_s_memrealtime();
-                    bool ok = true;
-                    for (;;) {
-                        const unsigned v = __hip_atomic_load(cp, T2_RLX_AGENT);
-                        if (__all(v >= want)) break;
-                        if (__builtin_amdgcn_s_memrealtime() - t0c > SPIN_TICKS) { ok = false; break; }
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                    if (!ok && lane == 0) { atomicMax(d.err, 12u); *abortw = 1; }
+                // K order of [W_ih | W_hh]: [h0 (H) | ctx0 (E) | h1 (H) | ctx1 (E) | dec_h (Hd)]; wave w covers k in [512 w, 512 w + 512).
+                // Every wave polls the one counter ITS slice hangs on (its loads are sc1 and follow its own poll): h_t and
+                // dec_h_{t-1} were published long ago, so six of the eight waves have their fragments in flight while the two
+                // ctx waves still wait for the attention phase
+                {
+                    const int kgw = wave * (DNW * 32), sg0 = H + Ee, sg1 = 2 * (H + Ee);
+                    const bool fd = kgw >= sg1;
+                    const int stw = kgw < sg0 ? 0 : 1;
+                    const bool isc = !fd && kgw - stw * sg0 >= H;
+                    const unsigned* cp = fd ? cntD : d.cnt + (size_t)(2 * stw + (isc ? 1 : 0)) * CNT_STRIDE;
+                    const unsigned want = fd ? ep * (unsigned)(Hd / DU) : isc ? (ep + 1) * (unsigned)(B * d.CS) : (ep + 1) * (unsigned)G.NUG;
+                    if (!poll_counter(cp, want, d.err, 12u) && lane == 0) *abortw = 1;
                 }
-                __syncthreads();
-                if (*abortw) return;
                 T2_CSTAMP(1);
-                // K order of [W_ih | W_hh]: [h0 (H) | ctx0 (E) | h1 (H) | ctx1 (E) | dec_h (Hd)]; wave w covers k in [512 w, 512 w + 512)
                 const int kg = wave * (DNW * 32);
                 const int seg0 = H + Ee, seg1 = 2 * (H + Ee);
                 const bool from_d = kg >= seg1;
@@ -817,6 +812,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) partDL[(wave * 32 + m * 16 + kq * 4 + e) * 20 + j16] = accd[m][e];
                 __syncthreads();
+                if (*abortw) return;
                 if (tid < 32 * DU) {
                     const int row = tid >> 2, uu = tid & 3;
                     float g4[4];
@@ -846,13 +842,13 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             }
             // =================================================================================== P1(t): mel / gate projections + stop rule (model.py:382-388, 461-480)
             if (hasP1) {
-                if (wave == 0 && !poll_counter(cntD, (ep + 1) * (unsigned)(Hd / DU), d.err, 13u) && lane == 0) *abortw = 1;
-                __syncthreads();
-                if (*abortw) return;
-                // K order of the projections: [dec_h (Hd) | ctx0 (E) | ctx1 (E)]; wave w covers k in [256 w, 256 w + 256)
+                // K order of the projections: [dec_h (Hd) | ctx0 (E) | ctx1 (E)]; wave w covers k in [256 w, 256 w + 256); as in
+                // D(t) every wave polls the counter of its own slice, so the ctx waves load while dec_h_t is still being made
                 const int kg = wave * 256;
                 const bool from_d = kg < Hd;
                 const int st = kg < Hd + Ee ? 0 : 1;
+                if (!poll_counter(from_d ? cntD : d.cnt + (size_t)(2 * st + 1) * CNT_STRIDE,
+                                  from_d ? (ep + 1) * (unsigned)(Hd / DU) : (ep + 1) * (unsigned)(B * d.CS), d.err, 13u) && lane == 0) *abortw = 1;
                 const int lk = from_d ? kg : H + (kg - Hd - st * Ee);                // ctx sits behind h in a stream's fragments
                 const unsigned base = from_d ? (unsigned)((t & 1) * (Hd / 16) * 1024) : xcur + (unsigned)st * G.xs_bytes;
                 f32x4 accp[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -878,6 +874,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) partDL[(wave * 32 + m * 16 + kq * 4 + e) * 20 + j16] = accp[m][e];
                 __syncthreads();
+                if (*abortw) return;
                 {
                     const int row = tid >> 4, col = p1g * 16 + (tid & 15);
                     float sum = 0.f;

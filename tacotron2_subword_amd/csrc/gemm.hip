@@ -11,6 +11,7 @@
 #include "kernels.h"
 #include <cstdlib>
 #include <algorithm>
+#include <type_traits>
 
 namespace t2 {
 
@@ -33,6 +34,7 @@ struct GemmK {
     int kchunks;    // K-chunks (of BK) per split
     int avec, bvec;  // 16-byte loads legal for A / B
     int xcd_swizzle; // bf16-source kernel: XCD-aware tile order (tile count a multiple of 8)
+    int dbg;         // development switches of the 256-tile kernel (T2_G256_DBG)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -770,6 +772,222 @@ int launch_bf16src(const GemmK& g, const __bf16* pa, long lda, const __bf16* pb,
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256 x 256 block tile, BK = 64, 8 waves as 2 (M) x 4 (N), each owning 128 x 64 of the tile as 4 x 2 MFMA tiles of
+// 32 x 32 (128 accumulator registers).  One workgroup per CU; 128 KB of LDS = 2 K-tiles x 4 half-tiles of 16 KB:
+//     A0 / A1: the first / second 64 rows of BOTH wave rows        B0 / B1: the first / second 32 columns of the 4 wave columns
+// so a half-tile holds what every wave needs for one operand of one quadrant of its output.  Operands go global -> LDS
+// with LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers); an instruction writes 1 KB = 8 rows of 128 B in lane
+// order, and the bank swizzle (16-byte chunk ^= (row >> 1) & 7: conflict-free ds_read_b128 of 32 rows x 2 chunks) is put on
+// the SOURCE address of each lane.
+//
+// K loop: 4 phases per K-tile, one output quadrant x K = 64 (8 MFMAs) each:
+//     phase   quadrant   fragment reads      LDS-DMA issued (one half-tile = 2 instructions per thread)
+//       0     (a0, b0)   A0, B0 of kt        B1 of kt+1
+//       1     (a0, b1)   B1 of kt            A1 of kt+1
+//       2     (a1, b1)   A1 of kt            A0 of kt+2
+//       3     (a1, b0)   -                   B0 of kt+2
+//   phase = { reads ; issue ; s_waitcnt vmcnt(8) ; s_barrier ; MFMAs ; s_barrier }: raw barriers and counted waits, so
+//   four half-tiles stay in flight across every barrier (a half-tile is read 5-6 phases after it was issued).  A staged
+//   buffer is read one phase after the wait + barrier that retires it and restaged at least two phases after its last
+//   read.  The two wave rows run one barrier apart (wave row 1 enters through an extra barrier), so on each SIMD one wave
+//   reads fragments while the other one issues MFMAs.  The last two K-tiles drain with vmcnt 4 / 2 / 0.
+// ---------------------------------------------------------------------------------------------
+template <bool CONV_A>
+__global__ __launch_bounds__(512) void gemm_bf16src256_kernel(GemmK g, const __bf16* __restrict__ A16, long lda, const __bf16* __restrict__ B16, long ldb) {
+    const GemmDesc& d = g.d;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (g.xcd_swizzle) {                                   // as gemm_bf16src_kernel: an XCD walks a contiguous run of tiles
+        const int gx = gridDim.x, gy = gridDim.y, total = gx * gy;
+        const int lin = by * gx + bx;
+        const int pid = (lin & 7) * (total >> 3) + (lin >> 3);
+        constexpr int GM = 4;
+        const int per_group = GM * gx, group = pid / per_group, first_m = group * GM;
+        const int gsz = min(gy - first_m, GM);
+        by = first_m + (pid % per_group) % gsz;
+        bx = (pid % per_group) / gsz;
+    }
+    const int m0 = by * 256, n0 = bx * 256, split = blockIdx.z;
+    const int kbeg = split * g.kchunks * BK, kend = min(d.K, kbeg + g.kchunks * BK);
+    const int nkt = (kend - kbeg) / 64;                    // even and >= 2 (launch site)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3, r = lane & 31, hk = lane >> 5;
+
+    // per-thread source offsets (bytes) of the two LDS-DMA instructions of each half-tile, swizzled
+    unsigned offA[2][2], offB[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int s = i * 512 + tid, hr = s >> 3, gc = (s & 7) ^ ((hr >> 1) & 7);
+            offA[h][i] = (unsigned)((((hr >> 6) * 128 + h * 64 + (hr & 63)) * lda + gc * 8) * 2);
+            offB[h][i] = (unsigned)((((hr >> 5) * 64 + h * 32 + (hr & 31)) * ldb + gc * 8) * 2);
+        }
+    auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(A16 + (long)m0 * lda + kbeg), 0, (int)(256 * lda * 2), 0x00020000);
+    auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(B16 + (long)n0 * ldb + kbeg), 0, (int)(256 * ldb * 2), 0x00020000);
+    // half-tile ht (0: A0, 1: A1, 2: B0, 3: B1) of K-tile kt -> LDS slot (kt & 1, ht)
+    auto stage = [&](int ht, int kt) {
+        unsigned char* dst = smem16 + (((kt & 1) * 4 + ht) << 14) + wave * 1024;
+        const int ko = (g.dbg & 1) ? 0 : kt * 128;
+        if (ht < 2) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)dst, 16, offA[ht][0], ko, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dst + 8192), 16, offA[ht][1], ko, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)dst, 16, offB[ht - 2][0], ko, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(dst + 8192), 16, offB[ht - 2][1], ko, 0, 0);
+        }
+    };
+    // fragment addresses inside a half-tile: row hr, 16-byte chunk c at hr * 128 + ((c ^ ((hr >> 1) & 7)) << 4)
+    const int sw = (r >> 1) & 7;
+    unsigned cofs[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) cofs[ks] = (unsigned)(((2 * ks + hk) ^ sw) << 4);
+    const unsigned rowA = (unsigned)((wr * 64 + r) * 128), rowB = (unsigned)((wc * 32 + r) * 128);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    bf16x8 Af[2][4], Bf[2][4];
+
+    auto read_a = [&](int buf, int h) {
+        const unsigned char* base = smem16 + ((buf * 4 + h) << 14) + rowA;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) Af[i][ks] = *reinterpret_cast<const bf16x8*>(base + i * 4096 + cofs[ks]);
+    };
+    auto read_b = [&](int buf, int h) {
+        const unsigned char* base = smem16 + ((buf * 4 + 2 + h) << 14) + rowB;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) Bf[h][ks] = *reinterpret_cast<const bf16x8*>(base + cofs[ks]);
+    };
+    auto mma = [&](int a, int b) {
+        if (g.dbg & 2) return;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[a * 2 + i][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[i][ks], Bf[b][ks], acc[a * 2 + i][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define T2_G256_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+    // one K-tile (buffer BUF): TAIL 0 = steady state, 1 = K-tile nkt-2, 2 = K-tile nkt-1
+    auto ktile = [&](auto bufc, auto tailc, int kt) {
+        constexpr int BUF = decltype(bufc)::value, TAIL = decltype(tailc)::value;
+        // phase 0
+        read_b(BUF, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(BUF, 0);
+        if (TAIL < 2) { stage(3, kt + 1); T2_G256_WAIT(8); } else T2_G256_WAIT(2);
+        __builtin_amdgcn_s_barrier();
+        mma(0, 0);
+        __builtin_amdgcn_s_barrier();
+        // phase 1
+        read_b(BUF, 1);
+        if (TAIL < 2) { stage(1, kt + 1); T2_G256_WAIT(8); } else T2_G256_WAIT(0);
+        __builtin_amdgcn_s_barrier();
+        mma(0, 1);
+        __builtin_amdgcn_s_barrier();
+        // phase 2
+        read_a(BUF, 1);
+        if (TAIL == 0) { stage(0, kt + 2); T2_G256_WAIT(8); }
+        __builtin_amdgcn_s_barrier();
+        mma(1, 1);
+        __builtin_amdgcn_s_barrier();
+        // phase 3
+        if (TAIL == 0) { stage(2, kt + 2); T2_G256_WAIT(8); } else if (TAIL == 1) T2_G256_WAIT(4);
+        __builtin_amdgcn_s_barrier();
+        mma(1, 0);
+        __builtin_amdgcn_s_barrier();
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+
+    // prologue: K-tile 0 and A0, B0 of K-tile 1
+    stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0); stage(0, 1); stage(2, 1);
+    T2_G256_WAIT(8);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    int kt = 0;
+    for (; kt + 2 < nkt; kt += 2) { ktile(I0{}, I0{}, kt); ktile(I1{}, I0{}, kt + 1); }
+    ktile(I0{}, I1{}, kt);
+    ktile(I1{}, I2{}, kt + 1);
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef T2_G256_WAIT
+
+    // Epilogue through LDS (free now): each wave lays 64 rows x 64 columns of its sub-tile out row-major in its own
+    // 16 KB and walks it with 16-byte reads, so a row leaves as 256 contiguous bytes and the per-row work (row map,
+    // dropout index base) is done once per 4 elements.
+    const RngKey key = rng_key(d.seed, d.site);
+    float* ws = d.splitk > 1 ? d.ws + (long)split * (long)d.M * d.N : nullptr;
+    float* stg = reinterpret_cast<float*>(smem16) + wave * 4096;
+    const bool vec_ok = ws || ((reinterpret_cast<uintptr_t>(d.C) & 15) == 0 && d.ldc % 4 == 0);
+    const float inv_keep = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
+    const int c4 = (lane & 15) * 4, n = n0 + wc * 64 + c4;
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (!ws) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bias[c] = (d.bias1 ? d.bias1[n + c] : 0.f) + (d.bias2 ? d.bias2[n + c] : 0.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) stg[(ii * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk) * 64 + j * 32 + r] = acc[2 * p + ii][j][e];
+        __syncthreads();
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 4 + (lane >> 4);
+            const int m = m0 + wr * 128 + p * 64 + row;
+            f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * 64 + c4);
+            if (ws) { *reinterpret_cast<f32x4*>(ws + (long)m * d.N + n) = v; continue; }
+            const uint32_t ibase = d.drop_base + (uint32_t)m * d.drop_mstride + (uint32_t)n;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float x = apply_act(d.alpha * v[c] + bias[c], d.act);
+                if (d.drop_p > 0.f) x = rng_keep(key, ibase + c, d.drop_p) ? x * inv_keep : 0.f;
+                v[c] = x;
+            }
+            const long mo = d.crow_mod ? (long)(m % d.crow_mod) * d.crow_mul + m / d.crow_mod : (long)m;
+            float* pc = d.C + mo * d.ldc + n;
+            if (vec_ok) {
+                if (d.beta != 0.f) v += d.beta * *reinterpret_cast<const f32x4*>(pc);
+                *reinterpret_cast<f32x4*>(pc) = v;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) pc[c] = d.beta != 0.f ? v[c] + d.beta * pc[c] : v[c];
+            }
+        }
+        if (p == 0) __syncthreads();
+    }
+}
+
+template <bool CONV_A>
+int launch_bf16src256(const GemmK& g, const __bf16* pa, long lda, const __bf16* pb, long ldb, int splitk, hipStream_t s) {
+    constexpr size_t smem = 128 * 1024;
+    static bool attr = false;
+    if (!attr) {
+        T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16src256_kernel<CONV_A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = true;
+    }
+    GemmK gk = g;
+    const int gx = g.d.N / 256, gy = g.d.M / 256;
+    gk.xcd_swizzle = (gx * gy) % 8 == 0 && gy >= 4;
+    static const int dbg = env_int("T2_G256_DBG", 0);
+    gk.dbg = dbg;
+    if (dbg & 4) gk.xcd_swizzle = 0;
+    hipLaunchKernelGGL((gemm_bf16src256_kernel<CONV_A>), dim3(gx, gy, splitk), dim3(512), smem, s, gk, pa, lda, pb, ldb);
+    T2_LAUNCH_CHECK();
+    return 0;
+}
+
 // staging casts: fp32 operand -> bf16 [rows][K] (K contiguous, leading dimension K)
 // k contiguous in the source: 8 elements per task
 __global__ void stage_kc_kernel(const float* __restrict__ src, long ld, __bf16* __restrict__ dst, int rows, int K) {
@@ -905,6 +1123,31 @@ int gemm(const GemmDesc& din, hipStream_t s) {
             if (need_a + need_b) { d.ws = reinterpret_cast<float*>(base + need_a + need_b); d.ws_bytes -= need_a + need_b; }
         }
     }
+    // 256 x 256 tiles (gemm_bf16src256_kernel) when the staged operands are whole 256-tiles and K splits into an even
+    // number of 64-wide K-tiles; its split-K factor fills whole rounds of one workgroup per CU
+    static const int g_t256 = env_int("T2_GEMM_256", 1);
+    bool use256 = staged && g_t256 && !conv_any && d.M % 256 == 0 && d.N % 256 == 0 && d.K % 128 == 0;
+    int split256 = 1;
+    if (use256) {
+        const long tiles = (long)(d.M / 256) * (d.N / 256);
+        const int nkt = d.K / 64;
+        if (d.splitk > 0) split256 = d.splitk;
+        else if (d.ws && d.beta == 0.f && tiles < 512) {
+            double best = 0.0;
+            for (int sp = 1; sp <= 16; sp *= 2) {
+                if (sp > 1 && nkt / sp < 16) break;
+                const long wgs = tiles * sp, rounds = (wgs + 255) / 256;
+                const double eff = (double)wgs / (256.0 * rounds);
+                if (eff > best * 1.05) { best = eff; split256 = sp; }
+            }
+        }
+        if (split256 > 1 && !(d.ws && d.beta == 0.f)) split256 = 1;
+        if (split256 > 1) {
+            const size_t per = (size_t)d.M * d.N * sizeof(float);
+            if ((size_t)split256 * per > d.ws_bytes) split256 = (int)(d.ws_bytes / per);
+            if (split256 < 1) split256 = 1;
+        }
+    }
     const int kch = (d.K + BK - 1) / BK;
     const bool can_split = d.ws && d.beta == 0.f && kch >= 64;
     const long tiles128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch;
@@ -928,8 +1171,10 @@ int gemm(const GemmDesc& din, hipStream_t s) {
         if ((size_t)splitk * per > d.ws_bytes) splitk = (int)(d.ws_bytes / per);
         if (splitk < 1) splitk = 1;
     }
+    if (use256) splitk = split256;
     g.kchunks = (kch + splitk - 1) / splitk;
     if (use_bf16) g.kchunks = (g.kchunks + 3) & ~3;   // whole 64-wide chunks per split
+    if (use256) g.kchunks = (g.kchunks + 7) & ~7;     // ... and an even number of them
     splitk = (kch + g.kchunks - 1) / g.kchunks;     // drop empty splits
     d.splitk = splitk;
     T2_REQUIRE((long)d.batch * splitk <= 65535, "gemm: batch*splitk too large (%d*%d)", d.batch, splitk);
@@ -950,7 +1195,8 @@ int gemm(const GemmDesc& din, hipStream_t s) {
         // 128x128 block tile, two k-steps in flight.  Measured alternatives (same template, other parameters): 256x128 with
         // 8 waves 5-12 % slower, 256x256 with 128x64 wave tiles and one k-step in flight 4.6x slower (one workgroup per CU:
         // nothing overlaps its barriers) — the kernel is bound by latency hiding, not by operand bytes per CU
-        if (d.conv_a) T2_TRY_RC((launch_bf16src<true, 2, 2, 2, 2, 2>(g, pa, lda, pb, ldb, splitk, s)));
+        if (use256) T2_TRY_RC((launch_bf16src256<false>(g, pa, lda, pb, ldb, splitk, s)));
+        else if (d.conv_a) T2_TRY_RC((launch_bf16src<true, 2, 2, 2, 2, 2>(g, pa, lda, pb, ldb, splitk, s)));
         else T2_TRY_RC((launch_bf16src<false, 2, 2, 2, 2, 2>(g, pa, lda, pb, ldb, splitk, s)));
     } else if (use_bf16) {
         const size_t smem = (size_t)4 * 128 * PK16 * sizeof(__bf16);
