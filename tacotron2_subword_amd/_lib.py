@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libt2amd.so")
+LIB_PATH = os.environ.get("T2AMD_LIB") or os.path.join(_HERE, "libt2amd.so")     # (T2AMD_LIB: development builds of the same library)
 
 ATTN_SMA, ATTN_LSA, ATTN_FWD2, ATTN_GMM, ATTN_DCA = 0, 1, 2, 3, 4
 

@@ -613,7 +613,7 @@ void bwd_layout_of(const t2_dims& d, const Sizes& z, t2_decoder_bwd_layout* L) {
     L->dmel_t = take(BT * z.M); L->dgate_t = take(BT);
     L->dg16a = take((size_t)2 * z.B * 4 * z.Ha / 2 + 4); L->dg16d = take((size_t)z.B * 4 * z.Hd / 2 + 4);
     L->colsum_ws = take((size_t)64 * 4 * (z.Ha > z.Hd ? z.Ha : z.Hd));
-    L->gemm_ws_floats = (size_t)128 << 20;                    // 512 MiB: split-K partials + bf16 operand staging (gemm.hip)
+    L->gemm_ws_floats = (size_t)192 << 20;                    // 768 MiB: split-K partials + bf16 operand staging (gemm.hip)
     L->gemm_ws = take(L->gemm_ws_floats);
     {   // persistent backward chains (chain_bwd.hip): [counters | dg fragments | K-split partials] of the decoder-LSTM chain,
         // then [counters | dg fragments | h partials | ctx partials | dq partials | boundary carries] of the attention chain

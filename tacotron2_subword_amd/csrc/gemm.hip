@@ -34,7 +34,6 @@ struct GemmK {
     int kchunks;    // K-chunks (of BK) per split
     int avec, bvec;  // 16-byte loads legal for A / B
     int xcd_swizzle; // bf16-source kernel: XCD-aware tile order (tile count a multiple of 8)
-    int dbg;         // development switches of the 256-tile kernel (T2_G256_DBG)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -793,6 +792,9 @@ int launch_bf16src(const GemmK& g, const __bf16* pa, long lda, const __bf16* pb,
 //   read.  The two wave rows run one barrier apart (wave row 1 enters through an extra barrier), so on each SIMD one wave
 //   reads fragments while the other one issues MFMAs.  The last two K-tiles drain with vmcnt 4 / 2 / 0.
 // ---------------------------------------------------------------------------------------------
+#ifndef T2_G256_PRIO
+#define T2_G256_PRIO 1
+#endif
 template <bool CONV_A>
 __global__ __launch_bounds__(512) void gemm_bf16src256_kernel(GemmK g, const __bf16* __restrict__ A16, long lda, const __bf16* __restrict__ B16, long ldb) {
     const GemmDesc& d = g.d;
@@ -811,8 +813,10 @@ __global__ __launch_bounds__(512) void gemm_bf16src256_kernel(GemmK g, const __b
     }
     const int m0 = by * 256, n0 = bx * 256, split = blockIdx.z;
     const int kbeg = split * g.kchunks * BK, kend = min(d.K, kbeg + g.kchunks * BK);
-    const int nkt = (kend - kbeg) / 64;                    // even and >= 2 (launch site)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3, r = lane & 31, hk = lane >> 5;
+    const int nkt = (kend - kbeg) / 64;                    // >= 2 (launch site)
+    const int nkt2 = (nkt + 1) & ~1;                       // the loop runs whole pairs: an odd count gets one K-tile of zeros
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (scalar: LDS-DMA bases live in SGPRs)
+    const int wr = wave >> 2, wc = wave & 3, r = lane & 31, hk = lane >> 5;
 
     // per-thread source offsets (bytes) of the two LDS-DMA instructions of each half-tile, swizzled
     unsigned offA[2][2], offB[2][2];
@@ -824,18 +828,46 @@ __global__ __launch_bounds__(512) void gemm_bf16src256_kernel(GemmK g, const __b
             offA[h][i] = (unsigned)((((hr >> 6) * 128 + h * 64 + (hr & 63)) * lda + gc * 8) * 2);
             offB[h][i] = (unsigned)((((hr >> 5) * 64 + h * 32 + (hr & 31)) * ldb + gc * 8) * 2);
         }
-    auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(A16 + (long)m0 * lda + kbeg), 0, (int)(256 * lda * 2), 0x00020000);
+    // CONV_A: A16 holds the frames X[M][C] (lda = C) and the operand is their implicit im2col: K-tile k0 lies inside tap
+    // dk = k0 / C (C % 64 == 0), so its rows are the frame rows shifted by dk - pad; a row that leaves its utterance gets
+    // an offset past the buffer's range, which the LDS-DMA fills with zeros.
+    const ConvAddr cva{d.conv_T, d.conv_C, d.conv_pad};
+    int tposA[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hr = (i * 512 + tid) >> 3;
+            tposA[h][i] = CONV_A ? (m0 + (hr >> 6) * 128 + h * 64 + (hr & 63)) % cva.T : 0;
+        }
+    int cdk[2], cka[2];                                    // tap and channel offset of the next K-tile of A half 0 / 1
+    cdk[0] = cdk[1] = CONV_A ? kbeg / cva.C : 0;
+    cka[0] = cka[1] = CONV_A ? kbeg % cva.C : 0;
+    auto rsA = CONV_A ? __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(A16), 0, (int)((long)d.M * lda * 2), 0x00020000)
+                      : __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(A16 + (long)m0 * lda + kbeg), 0, (int)(256 * lda * 2), 0x00020000);
     auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(B16 + (long)n0 * ldb + kbeg), 0, (int)(256 * ldb * 2), 0x00020000);
-    // half-tile ht (0: A0, 1: A1, 2: B0, 3: B1) of K-tile kt -> LDS slot (kt & 1, ht)
+    // half-tile ht (0: A0, 1: A1, 2: B0, 3: B1) of K-tile kt -> LDS slot (kt & 1, ht); the calls of one half come in kt order
     auto stage = [&](int ht, int kt) {
         unsigned char* dst = smem16 + (((kt & 1) * 4 + ht) << 14) + wave * 1024;
-        const int ko = (g.dbg & 1) ? 0 : kt * 128;
+        const int ko = kt * 128;
+        const bool live = kt < nkt;                        // (the padding K-tile of an odd count: offsets past the range read zeros)
         if (ht < 2) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)dst, 16, offA[ht][0], ko, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dst + 8192), 16, offA[ht][1], ko, 0, 0);
+            if constexpr (CONV_A) {
+                const int shift = cdk[ht] - cva.pad;
+                const unsigned rel = (unsigned)(((long)(m0 + shift) * lda + cka[ht]) * 2);      // (wraps for m0 + shift < 0: those rows are masked)
+                const unsigned o0 = live && (unsigned)(tposA[ht][0] + shift) < (unsigned)cva.T ? offA[ht][0] + rel : 0x80000000u;
+                const unsigned o1 = live && (unsigned)(tposA[ht][1] + shift) < (unsigned)cva.T ? offA[ht][1] + rel : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)dst, 16, o0, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dst + 8192), 16, o1, 0, 0, 0);
+                cka[ht] += 64;
+                if (cka[ht] == cva.C) { cka[ht] = 0; ++cdk[ht]; }
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)dst, 16, live ? offA[ht][0] : 0x80000000u, ko, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dst + 8192), 16, live ? offA[ht][1] : 0x80000000u, ko, 0, 0);
+            }
         } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)dst, 16, offB[ht - 2][0], ko, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(dst + 8192), 16, offB[ht - 2][1], ko, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)dst, 16, live ? offB[ht - 2][0] : 0x80000000u, ko, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(dst + 8192), 16, live ? offB[ht - 2][1] : 0x80000000u, ko, 0, 0);
         }
     };
     // fragment addresses inside a half-tile: row hr, 16-byte chunk c at hr * 128 + ((c ^ ((hr >> 1) & 7)) << 4)
@@ -867,13 +899,20 @@ __global__ __launch_bounds__(512) void gemm_bf16src256_kernel(GemmK g, const __b
         for (int ks = 0; ks < 4; ++ks) Bf[h][ks] = *reinterpret_cast<const bf16x8*>(base + cofs[ks]);
     };
     auto mma = [&](int a, int b) {
-        if (g.dbg & 2) return;
+#if T2_G256_PRIO
         __builtin_amdgcn_s_setprio(1);
+#else
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int i = 0; i < 2; ++i) acc[a * 2 + i][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[i][ks], Bf[b][ks], acc[a * 2 + i][b], 0, 0, 0);
+#if T2_G256_PRIO
         __builtin_amdgcn_s_setprio(0);
+#else
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     };
 #define T2_G256_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
     // one K-tile (buffer BUF): TAIL 0 = steady state, 1 = K-tile nkt-2, 2 = K-tile nkt-1
@@ -913,7 +952,7 @@ __global__ __launch_bounds__(512) void gemm_bf16src256_kernel(GemmK g, const __b
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();
     int kt = 0;
-    for (; kt + 2 < nkt; kt += 2) { ktile(I0{}, I0{}, kt); ktile(I1{}, I0{}, kt + 1); }
+    for (; kt + 2 < nkt2; kt += 2) { ktile(I0{}, I0{}, kt); ktile(I1{}, I0{}, kt + 1); }
     ktile(I0{}, I1{}, kt);
     ktile(I1{}, I2{}, kt + 1);
     if (wr == 0) __builtin_amdgcn_s_barrier();
@@ -980,9 +1019,6 @@ int launch_bf16src256(const GemmK& g, const __bf16* pa, long lda, const __bf16* 
     GemmK gk = g;
     const int gx = g.d.N / 256, gy = g.d.M / 256;
     gk.xcd_swizzle = (gx * gy) % 8 == 0 && gy >= 4;
-    static const int dbg = env_int("T2_G256_DBG", 0);
-    gk.dbg = dbg;
-    if (dbg & 4) gk.xcd_swizzle = 0;
     hipLaunchKernelGGL((gemm_bf16src256_kernel<CONV_A>), dim3(gx, gy, splitk), dim3(512), smem, s, gk, pa, lda, pb, ldb);
     T2_LAUNCH_CHECK();
     return 0;
@@ -1126,15 +1162,15 @@ int gemm(const GemmDesc& din, hipStream_t s) {
     // 256 x 256 tiles (gemm_bf16src256_kernel) when the staged operands are whole 256-tiles and K splits into an even
     // number of 64-wide K-tiles; its split-K factor fills whole rounds of one workgroup per CU
     static const int g_t256 = env_int("T2_GEMM_256", 1);
-    bool use256 = staged && g_t256 && !conv_any && d.M % 256 == 0 && d.N % 256 == 0 && d.K % 128 == 0;
+    const bool use256 = staged && g_t256 && d.M % 256 == 0 && d.N % 256 == 0 && d.K >= 128 && (!d.conv_a || (long)d.M * d.conv_C * 2 < (1l << 31));
     int split256 = 1;
     if (use256) {
         const long tiles = (long)(d.M / 256) * (d.N / 256);
         const int nkt = d.K / 64;
-        if (d.splitk > 0) split256 = d.splitk;
+        if (d.splitk > 0) split256 = std::min(d.splitk, std::max(1, nkt / 2));
         else if (d.ws && d.beta == 0.f && tiles < 512) {
             double best = 0.0;
-            for (int sp = 1; sp <= 16; sp *= 2) {
+            for (int sp = 1; sp <= 16; ++sp) {
                 if (sp > 1 && nkt / sp < 16) break;
                 const long wgs = tiles * sp, rounds = (wgs + 255) / 256;
                 const double eff = (double)wgs / (256.0 * rounds);
@@ -1174,8 +1210,12 @@ int gemm(const GemmDesc& din, hipStream_t s) {
     if (use256) splitk = split256;
     g.kchunks = (kch + splitk - 1) / splitk;
     if (use_bf16) g.kchunks = (g.kchunks + 3) & ~3;   // whole 64-wide chunks per split
-    if (use256) g.kchunks = (g.kchunks + 7) & ~7;     // ... and an even number of them
     splitk = (kch + g.kchunks - 1) / g.kchunks;     // drop empty splits
+    if (use256 && splitk > 1 && kch - (splitk - 1) * g.kchunks < 8) {   // the 256-tile kernel needs two K-tiles in every split
+        --splitk;
+        g.kchunks = ((kch + splitk - 1) / splitk + 3) & ~3;
+        splitk = (kch + g.kchunks - 1) / g.kchunks;
+    }
     d.splitk = splitk;
     T2_REQUIRE((long)d.batch * splitk <= 65535, "gemm: batch*splitk too large (%d*%d)", d.batch, splitk);
     dim3 grid(tn, tm, d.batch * splitk);
@@ -1195,7 +1235,8 @@ int gemm(const GemmDesc& din, hipStream_t s) {
         // 128x128 block tile, two k-steps in flight.  Measured alternatives (same template, other parameters): 256x128 with
         // 8 waves 5-12 % slower, 256x256 with 128x64 wave tiles and one k-step in flight 4.6x slower (one workgroup per CU:
         // nothing overlaps its barriers) — the kernel is bound by latency hiding, not by operand bytes per CU
-        if (use256) T2_TRY_RC((launch_bf16src256<false>(g, pa, lda, pb, ldb, splitk, s)));
+        if (use256 && d.conv_a) T2_TRY_RC((launch_bf16src256<true>(g, pa, lda, pb, ldb, splitk, s)));
+        else if (use256) T2_TRY_RC((launch_bf16src256<false>(g, pa, lda, pb, ldb, splitk, s)));
         else if (d.conv_a) T2_TRY_RC((launch_bf16src<true, 2, 2, 2, 2, 2>(g, pa, lda, pb, ldb, splitk, s)));
         else T2_TRY_RC((launch_bf16src<false, 2, 2, 2, 2, 2>(g, pa, lda, pb, ldb, splitk, s)));
     } else if (use_bf16) {

@@ -109,7 +109,10 @@ def test_conv_bn_stack_vs_oracle(env, kind, training):
 def test_conv_bn_stack_bf16_staged_vs_converting(env, training):
     """bf16 mode, whole-tile shapes: the conv GEMMs (forward, d(input), d(weight)) on staged bf16 operands (frames staged
     once, taps as row shifts; im2col transpose written out for d(weight)) against the same GEMMs on the converting
-    kernel — same operand rounding, so they agree to summation order, utterance edges included."""
+    kernel, utterance edges included.  Both round the same fp32 operands to bf16, but their K splits differ (the 256-tile
+    kernel keeps K whole where the converting kernel splits it), so layer 1 agrees to summation order (1e-6) and a few
+    elements of everything computed FROM it then round to the neighbouring bf16 value: 1e-3 of the largest element bounds
+    that; the independent check is test_conv_bf16_implicit_gemm_vs_fp64_on_rounded_operands below."""
     L, blocks, ops = env
     g = torch.Generator().manual_seed(11)
     B, T = 2, 128
@@ -136,10 +139,14 @@ def test_conv_bn_stack_bf16_staged_vs_converting(env, training):
         L.set_precision("f32")
     for a, b in zip(res[1], res[0]):
         assert torch.isfinite(a).all()
-        assert rel(a, b) < 2e-4
+        if float(b.abs().max()) < 1e-4:                              # d(conv bias) in front of a training-mode BatchNorm: exactly 0, rounding noise
+            assert float((a - b).abs().max()) < 1e-4
+        else:
+            assert rel(a, b) < 1e-3
 
 
-def test_conv_bf16_implicit_gemm_vs_fp64_on_rounded_operands(env):
+@pytest.mark.parametrize("B,T,Cin,Cout", [(2, 128, 128, 256), (3, 256, 256, 512)])
+def test_conv_bf16_implicit_gemm_vs_fp64_on_rounded_operands(env, B, T, Cin, Cout):
     """The bf16-source implicit-conv path (frames staged once as bf16, taps as row shifts, im2col transpose written out
     for d(weight)) against an INDEPENDENT reference: F.conv1d in fp64 on bf16-rounded x, w (forward) and bf16-rounded dz
     (both backward products) — the yardstick test_gemm_bf16_staged_operands uses for the plain GEMM.  Whole-tile shape
@@ -148,7 +155,6 @@ def test_conv_bf16_implicit_gemm_vs_fp64_on_rounded_operands(env):
     import torch.nn.functional as F
     L, blocks, ops = env
     g = torch.Generator().manual_seed(23)
-    B, T, Cin, Cout = 2, 128, 128, 256
     conv = torch.nn.Conv1d(Cin, Cout, 5, padding=2).cuda()
     bn = torch.nn.BatchNorm1d(Cout).cuda().eval()
     bn.running_mean.zero_(); bn.running_var.fill_(1.0 - bn.eps)

@@ -106,11 +106,12 @@ def test_gemm_bf16_operands(ops, M, N, K, ta, tb):
     assert L.get_precision() == "f32"
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 384, 192), (512, 256, 4096), (1024, 640, 64)])
+@pytest.mark.parametrize("M,N,K", [(256, 384, 192), (512, 256, 4096), (1024, 640, 64), (512, 512, 320), (256, 256, 128), (768, 256, 4160)])
 @pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, True), (True, False)])
 def test_gemm_bf16_staged_operands(ops, M, N, K, ta, tb):
-    """bf16 mode with scratch: whole-tile shapes take the bf16-source kernel (operands staged as bf16 copies, split-K for
-    the long K); same contract as the converting kernel, and the two agree to summation order."""
+    """bf16 mode with scratch: whole-tile shapes take the bf16-source kernels (operands staged as bf16 copies, split-K for
+    the long K) — whole 256-tiles the 256 x 256 LDS-DMA kernel (even, odd and minimal K-tile counts, with and without
+    split-K), the rest the 128 x 128 one; same contract as the converting kernel, and the two agree to summation order."""
     from tacotron2_subword_amd import _lib as L
     g = torch.Generator().manual_seed(M + N + K + 1)
     A = torch.randn((K, M) if ta else (M, K), generator=g).cuda()
@@ -128,3 +129,36 @@ def test_gemm_bf16_staged_operands(ops, M, N, K, ta, tb):
     ref = _ref(A.bfloat16().float(), B.bfloat16().float(), ta, tb) + bias.double().cpu()
     assert (C1.double().cpu() - ref).abs().max().item() < 2e-3 * max(1.0, K ** 0.5 / 8)
     assert (C1 - C0).abs().max().item() < 1e-4 * max(1.0, K ** 0.5)
+
+
+def test_gemm_bf16_tile256_epilogue(ops):
+    """The 256 x 256 kernel's LDS-staged epilogue: bias + activation + alpha, accumulate into C (beta), a strided C,
+    an explicit split-K — against fp64 on bf16-rounded operands."""
+    from tacotron2_subword_amd import _lib as L
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 512, 768, 1088                                     # 17 K-tiles (odd)
+    A = torch.randn(M, K, generator=g).cuda(); B = torch.randn(N, K, generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda(); C0 = torch.randn(M, N, generator=g).cuda()
+    ws = torch.empty(8 * M * N + (M + N) * K, device="cuda")
+    prod = A.bfloat16().double().cpu() @ B.bfloat16().double().cpu().t()
+    tol = 2e-3 * max(1.0, K ** 0.5 / 8)
+    L.set_precision("bf16")
+    try:
+        o1 = ops.gemm(A, B, bias=bias, act=1, alpha=0.5, ws=ws)
+        o2 = C0.clone(); ops.gemm(A, B, alpha=1.0, beta=2.0, out=o2, ws=ws)
+        big = torch.zeros(M, N + 64, device="cuda"); o3 = big[:, 32:32 + N]          # a strided C whose rows stay 16-byte aligned
+        raw = lambda out, b: L.check(L.lib().t2_gemm(A.data_ptr(), B.data_ptr(), out.data_ptr(), M, N, K, K, 1, K, 1, out.stride(0),
+                                                     b.data_ptr() if b is not None else None, 0, 1.0, 0.0, ws.data_ptr(), ws.numel() * 4, 0, L.stream()))
+        raw(o3, bias)
+        odd = torch.zeros(M, N + 3, device="cuda"); o4 = odd[:, 1:1 + N]             # rows that are NOT 16-byte aligned
+        raw(o4, None)
+        o5 = ops.gemm(A, B, ws=ws, splitk=3)
+    finally:
+        L.set_precision("f32")
+    assert (o1.double().cpu() - torch.relu(0.5 * prod + bias.double().cpu())).abs().max().item() < tol
+    assert (o2.double().cpu() - (prod + 2.0 * C0.double().cpu())).abs().max().item() < tol
+    assert (o3.double().cpu() - (prod + bias.double().cpu())).abs().max().item() < tol
+    assert big[:, :32].abs().max().item() == 0.0 and big[:, 32 + N:].abs().max().item() == 0.0
+    assert (o4.double().cpu() - prod).abs().max().item() < tol
+    assert odd[:, 0].abs().max().item() == 0.0 and odd[:, 1 + N:].abs().max().item() == 0.0
+    assert (o5.double().cpu() - prod).abs().max().item() < tol
