@@ -80,8 +80,8 @@ __host__ __device__ inline Lds lds_of(const ChainDesc& d, int UT, int RT, int Ti
     const int Tp = (Tin + 3) & ~3, EC = d.kind == CHAIN_LSTM ? 0 : d.E / d.CS;
     m.ab = take(4);
     if (d.kind != CHAIN_LSTM) {
-        m.v = take(d.A); m.ap = take(Tp + 4); m.cum = take(Tp + 4); m.q = take(d.A); m.e = take(Tp + 4); m.an = take(Tp + 4); m.cs = take(EC);
-        m.pm = take(Jp * d.A); m.mem = take(Jm * EC / 2);
+        m.v = take(d.A + 4); m.ap = take(Tp + 4); m.cum = take(Tp + 4); m.q = take(d.A); m.e = take(Tp + 4); m.an = take(Tp + 4); m.cs = take(EC);
+        m.pm = take(Jp * (d.kind == CHAIN_LSA ? d.A + 1 : d.A)); m.mem = take(Jm * EC / 2);    // (LSA reads pm position-major: odd pitch)
     } else { m.v = m.ap = m.cum = m.q = m.e = m.an = m.cs = m.pm = m.mem = o; }
     m.convw = m.dense = o;
     if (d.kind == CHAIN_LSA) { m.convw = take(d.F * 2 * d.Kc); m.dense = take(d.A * (d.F + 1)); }   // location layer weights, resident
@@ -93,7 +93,7 @@ __host__ __device__ inline Lds lds_of(const ChainDesc& d, int UT, int RT, int Ti
         const int TwP = (Tin + d.Kc - 1 + 4 + 3) & ~3;
         m.loc = aphase; aphase += (Tin * (d.F + 1) + 3) & ~3;
         m.wpad = aphase; aphase += 2 * TwP;
-        m.pa = aphase; aphase += Tin * (d.A + 8);
+        m.pa = aphase; aphase += (d.A / 32) * ((Tin + 3) & ~3);   // energy partials of the channel tiles [A/32][Tp]
     }
     m.scratch = take(lphase > aphase ? lphase : aphase);
     m.loc += m.scratch; m.wpad += m.scratch; m.pa += m.scratch;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
     float* redL = smem + M.scratch;                                    // [16][A]             (A phase)
     float* credL = smem + M.scratch + 16 * A;                          // [NWV][EC]
     float* convwL = smem + M.convw; float* denseL = smem + M.dense;    // LSA: [F][2][Kc], [A][F+1]
-    float* locL = smem + M.loc; float* wpadL = smem + M.wpad; float* paL = smem + M.pa;   // LSA: [Tin][F+1], [2][TwP], [Tin][A+8]
+    float* locL = smem + M.loc; float* wpadL = smem + M.wpad; float* paL = smem + M.pa;   // LSA: [Tin][F+1], [2][TwP], [A/32][Tp]
     (void)convwL; (void)denseL; (void)locL; (void)wpadL; (void)paL;
     (void)cumL; (void)qsL; (void)redL; (void)credL; (void)csL; (void)eL; (void)anL; (void)qL; (void)vL; (void)pmL; (void)memL;
 
@@ -185,6 +185,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
     int alen = 0;
     if (hasA) {
         for (int a = tid; a < A; a += NTH) vL[a] = AS.v[a];
+        if (tid == 0) { float sv = 0.f; for (int a = 0; a < A; ++a) sv += AS.v[a]; vL[A] = sv; }     // sum(v): e = sum(v) - 2 sum_a v_a / (exp(2u_a) + 1)
         for (int j = tid; j < Tp + 4; j += NTH) {
             float ap = 0.f, cm = 0.f;
             if (j < Tin) {
@@ -197,7 +198,9 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
         }
         for (int i = tid; i < Jp * (A / 4); i += NTH) {
             const int j = i / (A / 4), a4 = (i % (A / 4)) * 4;
-            *reinterpret_cast<f32x4*>(pmL + j * A + a4) = *reinterpret_cast<const f32x4*>(AS.pm + ((long)ab_ * Tin + j) * A + a4);
+            const f32x4 p4 = *reinterpret_cast<const f32x4*>(AS.pm + ((long)ab_ * Tin + j) * A + a4);
+            if (KIND == CHAIN_LSA) { float* pr = pmL + j * (A + 1) + a4; pr[0] = p4[0]; pr[1] = p4[1]; pr[2] = p4[2]; pr[3] = p4[3]; }
+            else *reinterpret_cast<f32x4*>(pmL + j * A + a4) = p4;
         }
         for (int i = tid; i < Jm * (EC / 4); i += NTH) {
             const int j = i / (EC / 4), c4 = (i % (EC / 4)) * 4;
@@ -511,6 +514,43 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
         if (hasA) {
             const int tid = tv, lane = tid & 63, wave = tid >> 6;
             T2_CSTAMP(6);
+            if (KIND == CHAIN_LSA) {
+                // ---- location features of [w_{t-1}; cum_{t-1}] (attention.py:7-23): conv (2 -> F channels, Kc taps, zero padded)
+                // on the matrix cores (exact fp32 fma chains).  It needs nothing of step t, so it runs HERE, in front of the poll:
+                // the workgroup would otherwise sit out the L phase's publish latency.  (The dense layer follows below, fused
+                // with the energies.)
+                const int F = d.F, Kc = d.Kc, F1 = F + 1, pad = (Kc - 1) / 2, Tw = Tin + Kc - 1, TwP = (Tw + 4 + 3) & ~3;
+                for (int i = tid; i < 2 * TwP; i += NTH) {
+                    const int c = i / TwP, j = i % TwP - pad;
+                    wpadL[i] = (j >= 0 && j < Tin) ? (c == 0 ? apL[j] : cumL[j]) : 0.f;
+                }
+                __syncthreads();
+                const int r_ = lane & 31, h_ = lane >> 5;
+                const int njt = (Tin + 31) / 32, nft = (F + 31) / 32;
+                // loc[j][f] = sum_{c,k} Wc[f][c][k] wpad[c][j + k]: a [Tin x 2Kc] . [2Kc x F] product whose A operand is read
+                // straight out of the padded weights (Toeplitz), K index ck = c*Kc + k
+                for (int tile = wave; tile < njt * nft; tile += NWV) {
+                    const int jt = tile / nft, ft = tile % nft;
+                    const float* xr = wpadL + min(jt * 32 + r_, Tin - 1);
+                    const float* wr = convwL + min(ft * 32 + r_, F - 1) * 2 * Kc;
+                    f32x16 acc;
+#pragma unroll
+                    for (int e2 = 0; e2 < 16; ++e2) acc[e2] = 0.f;
+                    for (int kk = 0; kk < 2 * Kc; kk += 2) {
+                        const int ck = kk + h_, c = ck >= Kc ? 1 : 0, k = ck - c * Kc;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[c * TwP + k], wr[ck], acc, 0, 0, 0);
+                    }
+                    const int f = ft * 32 + r_;
+                    if (f < F) {
+#pragma unroll
+                        for (int e2 = 0; e2 < 16; ++e2) {
+                            const int row = jt * 32 + (e2 & 3) + 8 * (e2 >> 2) + 4 * h_;
+                            if (row < Tin) locL[row * F1 + f] = acc[e2];
+                        }
+                    }
+                }
+                for (int j = tid; j < Tin; j += NTH) locL[j * F1 + F] = 0.f;         // pad column (K rounded up to even)
+            }
             if (wave == 0) {                          // h_t of the item's row group, and (one request) of the L item's for step t+1
                 const bool ok = (EARLY && hasL && more) ? poll_counters2(cntH_A, (ep + 1) * (unsigned)G.NUG, cntH_L, (ep + 1) * (unsigned)G.NUG, d.err, 3u)
                                                         : poll_counter(cntH_A, (ep + 1) * (unsigned)G.NUG, d.err, 3u);
@@ -552,55 +592,46 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 qL[tid] = sum;
                 if (!DEC && part == 0) AS.qs[((long)t * B + ab_) * A + tid] = sum;
             }
+            __syncthreads();
+            T2_CSTAMP(8);
             if (KIND == CHAIN_LSA) {
-                // ---- location features of [w_{t-1}; cum_{t-1}] (attention.py:7-23): conv (2 -> F channels, Kc taps, zero padded),
-                // then the dense layer on the matrix cores (exact fp32 fma chains), as attention.hip's LSA step
-                const int F = d.F, Kc = d.Kc, F1 = F + 1, pad = (Kc - 1) / 2, Tw = Tin + Kc - 1, TwP = (Tw + 4 + 3) & ~3;
-                for (int i = tid; i < 2 * TwP; i += NTH) {
-                    const int c = i / TwP, j = i % TwP - pad;
-                    wpadL[i] = (j >= 0 && j < Tin) ? (c == 0 ? apL[j] : cumL[j]) : 0.f;
-                }
-                __syncthreads();
-                const int nj4 = (Tin + 3) / 4;
-                for (int i = tid; i < nj4 * F; i += NTH) {              // one thread per (filter, 4 positions): sliding window in registers
-                    const int f = i % F, j0 = (i / F) * 4;
-                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                    for (int c = 0; c < 2; ++c) {
-                        const float* w = convwL + (f * 2 + c) * Kc;
-                        const float* xw = wpadL + c * TwP + j0;
-                        float x0 = xw[0], x1 = xw[1], x2 = xw[2];
-                        for (int k = 0; k < Kc; ++k) {
-                            const float x3 = xw[k + 3], wk = w[k];
-                            a0 += wk * x0; a1 += wk * x1; a2 += wk * x2; a3 += wk * x3;
-                            x0 = x1; x1 = x2; x2 = x3;
-                        }
-                    }
-                    locL[j0 * F1 + f] = a0;
-                    if (j0 + 1 < Tin) locL[(j0 + 1) * F1 + f] = a1;
-                    if (j0 + 2 < Tin) locL[(j0 + 2) * F1 + f] = a2;
-                    if (j0 + 3 < Tin) locL[(j0 + 3) * F1 + f] = a3;
-                }
-                for (int j = tid; j < Tin; j += NTH) locL[j * F1 + F] = 0.f;         // pad column (K rounded up to even)
-                __syncthreads();
+                // ---- LSA energies e_j = v . tanh(q + pm_j + dense(loc_j)) (attention.py:20-23, 73), dense layer and tanh fused:
+                // a wave takes a [32 channels x 32 positions] tile, pa^T = Wd . loc^T on the matrix cores (exact fp32 fma chains)
+                // with the POSITIONS on the lanes, so each lane sums its 16 channel rows in registers; the partials of the
+                // A/32 channel tiles meet in LDS ([A/32][Tp]).  pm rows are LDS-resident with an odd pitch (conflict-free
+                // position-major reads).
+                const int F1 = d.F + 1, Ke = (d.F + 1) & ~1, njt = (Tin + 31) / 32, nat = A / 32;
                 const int r_ = lane & 31, h_ = lane >> 5;
-                const int njt = (Tin + 31) / 32, nat = A / 32, Ke = (F + 1) & ~1;
+                constexpr float K2 = 2.0f * 1.44269504088896341f;
                 for (int tile = wave; tile < njt * nat; tile += NWV) {
-                    const int jt = tile / nat, at = tile % nat;
-                    const float* lr = locL + min(jt * 32 + r_, Tin - 1) * F1 + h_;
+                    const int jt = tile % njt, at = tile / njt;
+                    const int j = min(jt * 32 + r_, Tin - 1);
                     const float* dr = denseL + (at * 32 + r_) * F1 + h_;
+                    const float* lr = locL + j * F1 + h_;
                     f32x16 acc;
 #pragma unroll
                     for (int e2 = 0; e2 < 16; ++e2) acc[e2] = 0.f;
-                    for (int kk = 0; kk < Ke; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lr[kk], dr[kk], acc, 0, 0, 0);
+                    for (int kk = 0; kk < Ke; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dr[kk], lr[kk], acc, 0, 0, 0);
+                    const float* pr = pmL + j * (A + 1) + at * 32 + 4 * h_;
+                    const float* qr = qL + at * 32 + 4 * h_;
+                    const float* vr = vL + at * 32 + 4 * h_;
+                    float sum = 0.f;
 #pragma unroll
                     for (int e2 = 0; e2 < 16; ++e2) {
-                        const int row = jt * 32 + (e2 & 3) + 8 * (e2 >> 2) + 4 * h_;
-                        if (row < Tin) paL[row * (A + 8) + at * 32 + r_] = acc[e2];
+                        const int ao = (e2 & 3) + 8 * (e2 >> 2);
+                        const float x = qr[ao] + pr[ao] + acc[e2];
+                        sum += vr[ao] * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(K2 * x) + 1.0f);
                     }
+                    sum += __shfl_xor(sum, 32, 64);
+                    if (h_ == 0 && jt * 32 + r_ < Tin) paL[at * Tp + jt * 32 + r_] = sum;
                 }
-            }
-            __syncthreads();
-            T2_CSTAMP(8);
+                __syncthreads();
+                for (int jj = tid; jj < Tin; jj += NTH) {
+                    float sum = 0.f;
+                    for (int at = 0; at < nat; ++at) sum += paL[at * Tp + jj];
+                    eL[jj] = vL[A] - 2.0f * sum;
+                }
+            } else {
             // ---- energies e_j = v . tanh(q + pm_j) = sum(v) - 2 sum_a v_a / (exp(2 (q_a + pm_ja)) + 1): 16 lanes per position,
             // 8 channels per lane, two positions in flight per lane group
             {
@@ -618,10 +649,6 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 // LDS-resident rows and L2 rows go through separate loops: one loop with a choice per row makes hipcc
                 // select between the two pointers and read both through flat_load
                 auto dot = [&](f32x4 (&pv)[2], int j) {
-                    if (KIND == CHAIN_LSA) {                             // + dense(conv([w_prev; w_cum]))_j   (attention.py:20-23, 73)
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) pv[k] += *reinterpret_cast<const f32x4*>(paL + j * (A + 8) + sub * 4 + 64 * k);
-                    }
                     float sum = 0.f;
 #pragma unroll
                     for (int k = 0; k < 2; ++k)
@@ -655,6 +682,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                     for (int k = 0; k < 2; ++k) p0[k] = *reinterpret_cast<const f32x4*>(pr + 64 * k);
                     finish(j, dot(p0, j));
                 }
+            }
             }
             __syncthreads();
             T2_CSTAMP(9);
@@ -1017,10 +1045,12 @@ bool chain_plan(ChainDesc& d) {
     if (d.kind != CHAIN_LSTM) {
         const int EC = d.E / d.CS;
         int left = budget - fixed;
-        d.lds_Jp = std::min(tmax, left / d.A); left -= d.lds_Jp * d.A;
+        const int pmp = d.kind == CHAIN_LSA ? d.A + 1 : d.A;
+        d.lds_Jp = std::min(tmax, left / pmp); left -= d.lds_Jp * pmp;
+        if (d.kind == CHAIN_LSA && (d.lds_Jp < tmax || (d.dec && g.nA > 128))) return false;   // LSA energies read pm from LDS only
         d.lds_Jm = std::min(tmax, left / (EC / 2)) & ~1;
         for (int s = 0; s < d.NS; ++s) { d.Jp[s] = std::min(d.st[s].Tin, d.lds_Jp); d.Jm[s] = std::min(d.st[s].Tin, d.lds_Jm); }
-        if (getenv("T2_CHAIN_NO_RESIDENT")) { d.Jp[0] = d.Jp[1] = d.Jm[0] = d.Jm[1] = 0; }
+        if (getenv("T2_CHAIN_NO_RESIDENT")) { if (d.kind != CHAIN_LSA) d.Jp[0] = d.Jp[1] = 0; d.Jm[0] = d.Jm[1] = 0; }
         if (d.dec && (size_t)d.lds_Jp * d.A * 4 + (size_t)d.lds_Jm * EC * 2 < 64 * 1024) return false;     // (projection / prenet fragments live there)
     }
     return true;
