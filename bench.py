@@ -46,6 +46,7 @@ ATTENTION_NAMES = {"sma": "StepwiseMonotonicAttention", "lsa": "LSA", "fa2": "Fo
 # peaks from /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF headline is 2:1 sparse)
 
 
 def decoder_step_flops(hp, B, Tin, Tsub):
@@ -458,9 +459,42 @@ def main():
         # "decode steps/sec" half of BASELINE.json's metric: configs[3] (B=32, 1000 decoder steps, stop disabled)
         out["decode"] = decode_bench(model, hp, 32, Tin, Tsub, steps=1000, reps=2)
         out["gta"] = gta_bench(model, hp, T, 128, Tin, Tsub, Tn, reps=3)
+        if a.dtype == "bf16":
+            out["gemm"] = gemm_bench(B, Tn)
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)
+
+
+def gemm_bench(B, Tn, reps=10):
+    """The matrix-core side of the iteration: the two largest products of the decoder (hoisted decoder-LSTM input product
+    [B*T x 3072] . [4096 x 3072]^T and its weight gradient [4096 x B*T] . [B*T x 3072]) through the bf16-source GEMM, HIP
+    events on the launch stream; `kernel` = bf16 operand copies made beforehand (matrix kernel + split-K reduce alone)."""
+    import ctypes as C
+    from tacotron2_subword_amd import _lib as L
+    BT = B * Tn
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ws = torch.empty(192 << 20, device="cuda")
+    res = {}
+    for name, M, N, K, ta, tb in (("dec_lstm_input NT", BT, 4096, 3072, False, True), ("dec_lstm_dW TN", 4096, 3072, BT, True, False)):
+        A = torch.randn((K, M) if ta else (M, K), device="cuda", generator=g)
+        Bm = torch.randn((N, K) if tb else (K, N), device="cuda", generator=g)
+        out = torch.empty(M, N, device="cuda")
+        a = L.GemmArgs()
+        a.A, a.B, a.C, a.M, a.N, a.K = A.data_ptr(), Bm.data_ptr(), out.data_ptr(), M, N, K
+        a.sam, a.sak = (1, A.stride(0)) if ta else (A.stride(0), 1)
+        a.sbn, a.sbk = (Bm.stride(0), 1) if tb else (1, Bm.stride(0))
+        a.ldc, a.batch, a.alpha, a.beta = N, 1, 1.0, 0.0
+        a.ws, a.ws_bytes, a.splitk = ws.data_ptr(), ws.numel() * 4, 0
+        mt, mk = C.c_float(), C.c_float()
+        L.check(L.lib().t2_prof_gemm(C.byref(a), reps, C.byref(mt), C.byref(mk), L.stream()))
+        fl = 2.0 * M * N * K
+        res[name] = dict(M=M, N=N, K=K, kernel_us=round(1e3 * mk.value, 1), with_staging_us=round(1e3 * mt.value, 1),
+                         tflops=round(fl / mk.value / 1e9, 1), tflops_with_staging=round(fl / mt.value / 1e9, 1))
+    best = max(v["tflops"] for v in res.values())
+    return dict(bound="mfma", achieved=best, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(best / PEAK_BF16_TFLOPS, 4), products=res,
+                note="256x256-tile LDS-DMA kernel (csrc/gemm.hip), random operands; peak = dense bf16 MFMA rate of "
+                     "MI355X_MICROARCH.md; `with_staging` adds the fp32 -> bf16 operand casts of a cold call")
 
 
 def gta_bench(model, hp, T, B, Tin, Tsub, Tn, reps):

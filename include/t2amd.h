@@ -322,6 +322,10 @@ typedef struct t2_gemm_args {
     float* ws; size_t ws_bytes; int splitk;
 } t2_gemm_args;
 int t2_gemm_ex(const t2_gemm_args* a, void* stream);
+/* Measurement (bench.py): average milliseconds of `reps` launches of this product on `stream`, bracketed by HIP events —
+ * ms_total as t2_gemm_ex runs it (fp32 operands in: bf16 staging casts included), ms_kernel with both bf16 operand copies
+ * made beforehand (the matrix kernel and its split-K reduce alone).  bf16 mode, M, N multiples of 128, K of 64, scratch given. */
+int t2_prof_gemm(const t2_gemm_args* a, int reps, float* ms_total, float* ms_kernel, void* stream);
 /* out[n] = sum_m x[m*ld + n]; scratch >= 64*N floats */
 int t2_colsum(const float* x, long ld, int M, int N, float* out, float* scratch, void* stream);
 int t2_mask_btc(float* x, int B, int T, int C, const int32_t* lengths, float fill, void* stream);

@@ -153,7 +153,7 @@ class GemmArgs(C.Structure):
 EXPORTS = ["t2_last_error", "t2_version", "t2_set_precision", "t2_get_precision", "t2_set_overlap", "t2_set_chain", "t2_get_chain", "t2_set_chain_bwd", "t2_set_gemm_staging", "t2_side_join", "t2_decoder_layout_query", "t2_decoder_forward", "t2_decoder_infer",
            "t2_decoder_bwd_layout_query", "t2_decoder_backward", "t2_prof_enable", "t2_prof_collect", "t2_adam_chunks", "t2_adam_step", "t2_adam_norm",
            "t2_conv_bn_forward", "t2_conv_bn_backward", "t2_embedding_forward", "t2_embedding_backward",
-           "t2_lstm_seq_forward", "t2_lstm_seq_backward", "t2_gemm_ex", "t2_colsum", "t2_mask_btc",
+           "t2_lstm_seq_forward", "t2_lstm_seq_backward", "t2_gemm_ex", "t2_prof_gemm", "t2_colsum", "t2_mask_btc",
            "t2_finalize_bct", "t2_mask_bt", "t2_gemm", "t2_rng_keep_mask", "t2_rng_normal"]
 
 _lib = None
@@ -185,6 +185,7 @@ def lib() -> C.CDLL:
         L.t2_lstm_seq_forward.argtypes = [C.POINTER(LstmSeqArgs), C.c_void_p]
         L.t2_lstm_seq_backward.argtypes = [C.POINTER(LstmSeqBwdArgs), C.c_void_p]
         L.t2_gemm_ex.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
+        L.t2_prof_gemm.argtypes = [C.POINTER(GemmArgs), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p]
         L.t2_colsum.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.t2_mask_btc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p]
         L.t2_prof_enable.argtypes = [C.c_int]

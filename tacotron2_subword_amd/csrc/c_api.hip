@@ -1493,6 +1493,48 @@ int t2_gemm_ex(const t2_gemm_args* a, void* stream) {
     g.ws = a->ws; g.ws_bytes = a->ws_bytes; g.splitk = a->splitk;
     return gemm(g, (hipStream_t)stream);
 }
+// bench.py's GEMM roofline figure: `reps` launches of one product bracketed by HIP events on the launch stream, once as
+// t2_gemm_ex runs it (fp32 operands in, staging casts included) and once with both bf16 operand copies made beforehand,
+// so that the second figure is the matrix kernel (+ its split-K reduce) alone.
+int t2_prof_gemm(const t2_gemm_args* a, int reps, float* ms_total, float* ms_kernel, void* stream) {
+    T2_REQUIRE(a && reps > 0 && ms_total && ms_kernel, "t2_prof_gemm: bad arguments");
+    T2_REQUIRE(get_precision() == 1 && a->M % 128 == 0 && a->N % 128 == 0 && a->K % 64 == 0 && (a->batch <= 1) && a->ws,
+               "t2_prof_gemm: bf16 mode, whole-tile shapes and scratch only");
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    T2_CHECK_HIP(hipEventCreate(&e0)); T2_CHECK_HIP(hipEventCreate(&e1));
+    int rc = t2_gemm_ex(a, stream);                                       // warm-up
+    T2_CHECK_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < reps && rc == 0; ++i) rc = t2_gemm_ex(a, stream);
+    T2_CHECK_HIP(hipEventRecord(e1, s));
+    T2_CHECK_HIP(hipEventSynchronize(e1));
+    T2_CHECK_HIP(hipEventElapsedTime(ms_total, e0, e1));
+    *ms_total /= reps;
+    if (rc == 0) {
+        const size_t na = ((size_t)a->M * a->K * sizeof(__bf16) + 255) & ~(size_t)255, nb = ((size_t)a->N * a->K * sizeof(__bf16) + 255) & ~(size_t)255;
+        T2_REQUIRE(a->ws_bytes > na + nb, "t2_prof_gemm: scratch too small");
+        unsigned char* w8 = reinterpret_cast<unsigned char*>(a->ws);
+        __bf16* a16 = reinterpret_cast<__bf16*>(w8); __bf16* b16 = reinterpret_cast<__bf16*>(w8 + na);
+        const bool akc = a->sak == 1, bkc = a->sbk == 1;
+        rc = stage_bf16(a->A, akc, akc ? a->sam : a->sak, a16, a->M, a->K, s);
+        if (rc == 0) rc = stage_bf16(a->B, bkc, bkc ? a->sbn : a->sbk, b16, a->N, a->K, s);
+        GemmDesc g = gemm_desc();
+        g.A = a->A; g.B = a->B; g.C = a->C; g.M = a->M; g.N = a->N; g.K = a->K;
+        g.sam = a->sam; g.sak = a->sak; g.sbn = a->sbn; g.sbk = a->sbk; g.ldc = a->ldc;
+        g.alpha = a->alpha; g.beta = a->beta; g.bias1 = a->bias; g.act = a->act; g.splitk = a->splitk;
+        g.A16 = a16; g.lda16 = a->K; g.B16 = b16; g.ldb16 = a->K;
+        g.ws = reinterpret_cast<float*>(w8 + na + nb); g.ws_bytes = a->ws_bytes - na - nb;
+        if (rc == 0) rc = gemm(g, s);
+        T2_CHECK_HIP(hipEventRecord(e0, s));
+        for (int i = 0; i < reps && rc == 0; ++i) rc = gemm(g, s);
+        T2_CHECK_HIP(hipEventRecord(e1, s));
+        T2_CHECK_HIP(hipEventSynchronize(e1));
+        T2_CHECK_HIP(hipEventElapsedTime(ms_kernel, e0, e1));
+        *ms_kernel /= reps;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return rc;
+}
 int t2_colsum(const float* x, long ld, int M, int N, float* out, float* scratch, void* stream) {
     return colsum(x, ld, M, N, out, nullptr, scratch, (hipStream_t)stream);
 }
