@@ -323,7 +323,7 @@ def main():
     fresh = None
     if extras:
         hb = host_batches(T, hp, B, Tin, Tsub, Tn, 4, seed=4321)
-        for i in range(2):
+        for i in range(2 * len(hb)):                                    # steady state: every host batch through both staging slots of the ring
             xf, yf = model.parse_batch(D.batch_to_device(hb[i % 4]))
             T.train_step(model, criterion, optimizer, xf, yf, hp, it)
         torch.cuda.synchronize()
