@@ -23,3 +23,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv 
 echo "pmc traffic done"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o pm -- python3 $R/scripts/time_decoder.py --T 400 --iters 1 --prof 0 > $O/pmc_mfma.log 2>&1 < /dev/null
 echo "pmc done"
+# GEMM (256-tile LDS-DMA kernel): per-shape kernel durations, MFMA issue, fabric-side traffic
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_gemm -o gp -- python3 $R/scripts/check_gemm256.py --notest --reps 1 > $O/prof_gemm.log 2>&1 < /dev/null
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_gemm_mfma -o gm -- python3 $R/scripts/check_gemm256.py --notest --reps 1 > $O/pmc_gemm_mfma.log 2>&1 < /dev/null
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_gemm_fetch -o gf -- python3 $R/scripts/check_gemm256.py --notest --reps 1 > $O/pmc_gemm_fetch.log 2>&1 < /dev/null
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_gemm_write -o gw -- python3 $R/scripts/check_gemm256.py --notest --reps 1 > $O/pmc_gemm_write.log 2>&1 < /dev/null
+echo "gemm profiles done"

@@ -162,3 +162,30 @@ def test_gemm_bf16_tile256_epilogue(ops):
     assert (o4.double().cpu() - prod).abs().max().item() < tol
     assert odd[:, 0].abs().max().item() == 0.0 and odd[:, 1 + N:].abs().max().item() == 0.0
     assert (o5.double().cpu() - prod).abs().max().item() < tol
+
+
+def test_prof_gemm_times_and_result(ops):
+    """t2_prof_gemm (bench.py's GEMM figure): both timed variants leave the product in C and report positive times;
+    the pre-staged variant is not slower than the one that casts its operands on every call."""
+    import ctypes as C
+    from tacotron2_subword_amd import _lib as L
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 1024, 512, 768
+    A = torch.randn(M, K, generator=g).cuda(); B = torch.randn(N, K, generator=g).cuda()
+    out = torch.zeros(M, N, device="cuda")
+    ws = torch.empty(8 << 20, device="cuda")
+    a = L.GemmArgs()
+    a.A, a.B, a.C, a.M, a.N, a.K = A.data_ptr(), B.data_ptr(), out.data_ptr(), M, N, K
+    a.sam, a.sak, a.sbn, a.sbk, a.ldc, a.batch, a.alpha, a.beta = K, 1, K, 1, N, 1, 1.0, 0.0
+    a.ws, a.ws_bytes, a.splitk = ws.data_ptr(), ws.numel() * 4, 0
+    mt, mk = C.c_float(), C.c_float()
+    L.set_precision("bf16")
+    try:
+        L.check(L.lib().t2_prof_gemm(C.byref(a), 5, C.byref(mt), C.byref(mk), L.stream()))
+    finally:
+        L.set_precision("f32")
+    ref = A.bfloat16().double().cpu() @ B.bfloat16().double().cpu().t()
+    assert (out.double().cpu() - ref).abs().max().item() < 2e-3 * max(1.0, K ** 0.5 / 8)
+    assert 0.0 < mk.value <= mt.value * 1.5 and mt.value < 50.0
+    with pytest.raises(RuntimeError):                                   # fp32 mode: refused, not silently timed
+        L.check(L.lib().t2_prof_gemm(C.byref(a), 5, C.byref(mt), C.byref(mk), L.stream()))
