@@ -602,8 +602,9 @@ void bwd_layout_of(const t2_dims& d, const Sizes& z, t2_decoder_bwd_layout* L) {
     const bool lsa = d.attention_kind == T2_ATTN_LSA;          // LSA: cumulative-weight carry + per-item location-layer gradients
     const bool gmm = d.attention_kind == T2_ATTN_GMM;          // GMM: mean carry [B,8] + per-item db2 [B,16] / dW2 [B,3K*A]
     const bool dca = d.attention_kind == T2_ATTN_DCA;          // DCA: all per-item accumulators in one block (dldense)
-    const size_t ncv = lsa ? (size_t)z.B * d.loc_filters * 2 * d.loc_kernel : gmm ? (size_t)z.B * 16 : 0;
-    const size_t nds = lsa ? (size_t)z.B * z.A * d.loc_filters : gmm ? (size_t)z.B * 3 * kGmmK * z.A : dca ? (size_t)z.B * dca_acc_floats(z.A) : 0;
+    // (LSA: two rows per item — the persistent backward chain keeps one accumulator per position split)
+    const size_t ncv = lsa ? (size_t)2 * z.B * d.loc_filters * 2 * d.loc_kernel : gmm ? (size_t)z.B * 16 : 0;
+    const size_t nds = lsa ? (size_t)2 * z.B * z.A * d.loc_filters : gmm ? (size_t)z.B * 3 * kGmmK * z.A : dca ? (size_t)z.B * dca_acc_floats(z.A) : 0;
     L->carryc = take(lsa ? (size_t)z.B * z.Tin : gmm ? (size_t)z.B * kGmmPad : 0); L->carrycs = take(lsa ? (size_t)z.B * z.Tsub : gmm ? (size_t)z.B * kGmmPad : 0);
     L->dlconv = take(ncv); L->dlconvs = take(ncv); L->dldense = take(nds); L->dldenses = take(nds);
     L->dcd = take((size_t)z.B * z.Hd); L->dca = take((size_t)z.B * z.Ha); L->dcas = take((size_t)z.B * z.Ha);
@@ -620,7 +621,8 @@ void bwd_layout_of(const t2_dims& d, const Sizes& z, t2_decoder_bwd_layout* L) {
         ChainBwdDesc cd{}; cd.kind = CHAIN_LSTM; cd.B = z.B; cd.H = z.Hd;
         size_t xb = 0, pb = 0;
         chain_bwd_exchange_bytes(cd, &xb, &pb);
-        ChainBwdDesc ca{}; ca.kind = CHAIN_SMA; ca.B = z.B; ca.H = z.Ha; ca.E = z.E; ca.A = z.A; ca.NS = z.NS;
+        ChainBwdDesc ca{}; ca.kind = lsa ? CHAIN_LSA : CHAIN_SMA; ca.B = z.B; ca.H = z.Ha; ca.E = z.E; ca.A = z.A; ca.NS = z.NS;
+        ca.F = d.loc_filters; ca.Kc = d.loc_kernel;
         size_t x2, ph, pc, dq, cr;
         const size_t att = chain_bwd_att_exchange_bytes(ca, &x2, &ph, &pc, &dq, &cr);
         L->chain_floats = (2 * kChainBwdCntBytes + xb + pb + att + 255) / sizeof(float);
@@ -720,9 +722,11 @@ bool chain_b_bwd_desc(const Bwd& c, ChainBwdDesc* out) {
 // Persistent BPTT of the attention chain (both attention LSTMs + SMA attention); false = not covered
 bool chain_a_bwd_desc(const Bwd& c, ChainBwdDesc* out) {
     const Sizes& z = c.z;
-    if (!c.use16 || c.d.attention_kind != T2_ATTN_SMA || attn_bwd_nsplit(c.d, z) != 2) return false;
+    const bool lsa = c.d.attention_kind == T2_ATTN_LSA;
+    if (!c.use16 || !(lsa || (c.d.attention_kind == T2_ATTN_SMA && attn_bwd_nsplit(c.d, z) == 2))) return false;
     ChainBwdDesc d{};
-    d.NS = z.NS; d.B = z.B; d.T = z.T; d.H = z.Ha; d.E = z.E; d.A = z.A; d.kind = CHAIN_SMA;
+    d.NS = z.NS; d.B = z.B; d.T = z.T; d.H = z.Ha; d.E = z.E; d.A = z.A; d.kind = lsa ? CHAIN_LSA : CHAIN_SMA;
+    d.F = c.d.loc_filters; d.Kc = c.d.loc_kernel;
     d.drop_p = c.a.training ? c.d.p_att_dropout : 0.f; d.seed = c.a.seed;
     for (int s = 0; s < z.NS; ++s) {
         ChainBwdStream& st = d.st[s];
@@ -742,6 +746,10 @@ bool chain_a_bwd_desc(const Bwd& c, ChainBwdDesc* out) {
         st.v = aw.v; st.wq = aw.wq;
         st.dctx_out = c.S(s ? c.BL.dctxs : c.BL.dctx); st.dq_out = c.S(s ? c.BL.dqs : c.BL.dq);
         st.dv_acc = c.S(s ? c.BL.dvs : c.BL.dv); st.dpm_acc = c.S(s ? c.BL.dpms : c.BL.dpm);
+        if (lsa) {
+            st.wcum = c.W(s ? c.L.wcums : c.L.wcum); st.loc_conv = aw.loc_conv; st.loc_dense = aw.loc_dense;
+            st.dconv_acc = c.S(s ? c.BL.dlconvs : c.BL.dlconv); st.ddense_acc = c.S(s ? c.BL.dldenses : c.BL.dldense);
+        }
     }
     if (!chain_bwd_plan(d)) return false;
     ChainBwdDesc cd{}; cd.kind = CHAIN_LSTM; cd.B = z.B; cd.H = z.Hd;
@@ -757,6 +765,9 @@ bool chain_a_bwd_desc(const Bwd& c, ChainBwdDesc* out) {
     d.PBC = p; p += pc; d.pbc_bytes = (unsigned)(2 * (size_t)z.NS * 4 * z.B * z.E * sizeof(float));
     d.DQX = reinterpret_cast<float*>(p); p += dq;
     d.CARRYX = reinterpret_cast<float*>(p);
+    if (lsa)                                                              // bf16 Wd^T copies behind the tagged part (filled by the caller)
+        for (int s = 0; s < z.NS; ++s)
+            d.st[s].wdt16 = reinterpret_cast<const __bf16*>(p + chain_bwd_lsa_tagged_bytes(d)) + (size_t)s * d.F * d.A;
     d.err = reinterpret_cast<unsigned*>(const_cast<float*>(c.a.ws) + c.L.chain) + 3;      // status word 3 of the forward block
     *out = d;
     return true;
@@ -1132,6 +1143,9 @@ int t2_decoder_backward(const t2_dims* dims_in, const t2_decoder_weights* w, con
         }
         if (chain_a) {
             cab.t0 = t0; cab.t1 = t1;
+            if (cab.kind == CHAIN_LSA)
+                for (int s = 0; s < z.NS; ++s)                            // [A][F] -> bf16 [F][A]
+                    T2_TRY(cast_transpose_bf16(cab.st[s].loc_dense, cab.F, const_cast<__bf16*>(cab.st[s].wdt16), z.A, z.A, cab.F, c.s));
             ProfScope ps(PK_CHAIN_A_BWD, c.s);
             T2_TRY(chain_bwd(cab, c.s));
         } else {
@@ -1200,7 +1214,8 @@ int t2_decoder_backward(const t2_dims* dims_in, const t2_decoder_weights* w, con
         T2_TRY(relu_drop_bwd(dP1, P1, dP1, scale, (size_t)BT * z.P, ts));
         T2_TRY(gemm(matmul_tn(c, dP1, z.P, c.W(L.x), z.M, s ? g->prenet_sub_w1 : g->prenet_w1, z.M, z.P, z.M, BT), ts));
         // attention parameters
-        const int nsp = attn_bwd_nsplit(*dims, z);
+        const bool lsa_chain = chain_a && cab.kind == CHAIN_LSA;          // the persistent LSA backward: one partial per position split
+        const int nsp = lsa_chain ? 2 : attn_bwd_nsplit(*dims, z);
         float* DQ = c.S(s ? BL.dqs : BL.dq);
         if (nsp == 2) T2_TRY(fold_halves(DQ, BT, z.A, ts));               // dq row = partial 0 + partial 1
         T2_TRY(gemm(matmul_tn(c, DQ, 2 * z.A, DIN + hoff, z.WD, ag.wq, z.Ha, z.A, z.Ha, BT), ts));
@@ -1237,8 +1252,8 @@ int t2_decoder_backward(const t2_dims* dims_in, const t2_decoder_weights* w, con
         }
         if (dims->attention_kind == T2_ATTN_LSA) {
             T2_REQUIRE(ag.loc_conv && ag.loc_dense, "t2_decoder_backward: LSA needs loc_conv / loc_dense gradient buffers");
-            T2_TRY(batch_sum(c.S(s ? BL.dlconvs : BL.dlconv), z.B, dims->loc_filters * 2 * dims->loc_kernel, ag.loc_conv, ts));
-            T2_TRY(batch_sum(c.S(s ? BL.dldenses : BL.dldense), z.B, z.A * dims->loc_filters, ag.loc_dense, ts));
+            T2_TRY(batch_sum(c.S(s ? BL.dlconvs : BL.dlconv), (lsa_chain ? 2 : 1) * z.B, dims->loc_filters * 2 * dims->loc_kernel, ag.loc_conv, ts));
+            T2_TRY(batch_sum(c.S(s ? BL.dldenses : BL.dldense), (lsa_chain ? 2 : 1) * z.B, z.A * dims->loc_filters, ag.loc_dense, ts));
         }
         const float* mem = s ? a->memory_sub : a->memory;
         float* dmem = s ? a->d_memory_sub : a->d_memory;

@@ -230,23 +230,32 @@ __global__ __launch_bounds__(NTH) void chain_bwd_lstm_kernel(ChainBwdDesc d) {
 constexpr int ANC = 64;          // output columns of a G item (attention chain)
 constexpr int AKP = 4;           // K parts = the four gate blocks
 
-struct BwdLds { int ab, v, q, dctx, g, de, ps, ap, carry, dva, dqo, wq, pm, dpm, mem, scratch, total; };
-__host__ __device__ inline BwdLds bwd_lds_of(int A, int E, int Tc, int MT) {
+struct BwdLds { int ab, v, q, dctx, g, de, ps, ap, carry, dva, dqo, wq, pm, dpm, mem, cc, convw, dloc, wpad, ut, loc, red, TwP, scratch, total; };
+__host__ __device__ inline BwdLds bwd_lds_of(int A, int E, int Tc, int MT, int kind = CHAIN_SMA, int F = 0, int Kc = 1) {
     BwdLds m; int o = 0;
     auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+    const bool lsa = kind == CHAIN_LSA;
+    const int pad = (Kc - 1) / 2;
     m.ab = take(4); m.v = take(A); m.q = take(A); m.dctx = take(E);
     m.g = take(Tc + 8); m.de = take(Tc + 8); m.ps = take(Tc + 8); m.ap = take(Tc + 8); m.carry = take(Tc + 8);
     m.dva = take(A); m.dqo = take(A);
     m.wq = take(PU * (A + 4));
-    m.pm = take(Tc * A); m.dpm = take(Tc * A); m.mem = take((Tc + 1) * E / 2);
-    const int sg = NWV * 32 * PPR, sp = 32 * (A + 4) + 4 * 32 * (PU + 4), sa = 2 * 32 * A;
+    m.pm = take(lsa ? 0 : Tc * A); m.dpm = take(Tc * A); m.mem = take((Tc + 1) * E / 2);
+    // LSA: carried gradient on the cumulative weights, conv weights, dloc of the last step with `pad` halo rows on both
+    // sides (pitch F + 1, column F stays zero), [w_prev; cum_prev] of two steps (ping-pong) with the same halos
+    m.TwP = (Tc + 2 * pad + 3) & ~3;
+    m.cc = take(lsa ? Tc + 8 : 0); m.convw = take(lsa ? F * 2 * Kc : 0); m.dloc = take(lsa ? (Tc + 2 * pad) * (F + 1) : 0);
+    m.wpad = take(lsa ? 4 * m.TwP : 0);
+    // scratch shared by the phases; LSA's A phase: tanh / dpre tile [Tc][A + 4], location features [Tc][F + 1], reduction rows
+    m.ut = 0; m.loc = (Tc * (A + 4) + 3) & ~3; m.red = m.loc + ((Tc * (F + 1) + 3) & ~3);
+    const int sg = NWV * 32 * PPR, sp = 32 * (A + 4) + 4 * 32 * (PU + 4), sa = lsa ? m.red + 2 * NWV * A : 2 * 32 * A;
     m.scratch = take(sg > sp ? (sg > sa ? sg : sa) : (sp > sa ? sp : sa));
     m.total = o;
     return m;
 }
 
-template <int MT>
-__global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
+template <int MT, int KIND>
+__global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
     const int wg = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hk = lane >> 5;
     const int B = d.B, H = d.H, K4 = 4 * H, E = d.E, A = d.A, N = E + H;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -264,8 +273,8 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
     const int Tin = AS.Tin;
     const int chunk = (((Tin + 1) / 2) + 3) & ~3;
     const int jb = min(split * chunk, Tin), je = min(jb + chunk, Tin), len = je - jb;
-    const int ng = je < Tin ? len + 1 : len;                   // g values computed here: positions [jb, jb + ng)
-    const BwdLds M = bwd_lds_of(A, E, d.lds_Tc, MT);
+    const int ng = (KIND == CHAIN_SMA && je < Tin) ? len + 1 : len;   // g values computed here: positions [jb, jb + ng)
+    const BwdLds M = bwd_lds_of(A, E, d.lds_Tc, MT, KIND, d.F, d.Kc);
     unsigned* abortw = reinterpret_cast<unsigned*>(smem + M.ab);
     float* vL = smem + M.v; float* qL = smem + M.q; float* dctxL = smem + M.dctx; float* gL = smem + M.g; float* deL = smem + M.de;
     float* psL = smem + M.ps; float* apL = smem + M.ap; float* carryL = smem + M.carry; float* dvaL = smem + M.dva; float* dqoL = smem + M.dqo;
@@ -282,7 +291,9 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
     auto rsH = __builtin_amdgcn_make_buffer_rsrc(d.PB, 0, (int)d.pb_bytes, 0x00020000);
     auto rsC = __builtin_amdgcn_make_buffer_rsrc(d.PBC, 0, (int)d.pbc_bytes, 0x00020000);
     auto rsQ = __builtin_amdgcn_make_buffer_rsrc(d.DQX, 0, d.NS * 2 * B * A * 4, 0x00020000);
-    auto rsK = __builtin_amdgcn_make_buffer_rsrc(d.CARRYX, 0, 2 * d.NS * B * 4, 0x00020000);
+    // SMA: one boundary-carry float per (parity, stream, item).  LSA: [parity][stream][item][split][pad][F] halo rows of dloc, then
+    // [parity][stream][item][split] (softmax-dot partial, step tag)
+    auto rsK = __builtin_amdgcn_make_buffer_rsrc(d.CARRYX, 0, KIND == CHAIN_LSA ? (((d.Kc - 1) / 2) * d.F + 2) * 2 * d.NS * B * 2 * 4 : 2 * d.NS * B * 4, 0x00020000);
     const unsigned pbh_half = d.pb_bytes / 2, pbc_half = d.pbc_bytes / 2;
     const unsigned pbh_kp = (unsigned)((H / PU) * MT * 32 * PU * 4), pbh_s = pbh_kp * AKP;     // bytes per K part / per stream
     const unsigned pbc_kp = (unsigned)(B * E * 4), pbc_s = pbc_kp * AKP;
@@ -320,14 +331,31 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
         load_pin(d.t1 - 1, tid);
     }
     // ---------------------------------------------------------------- A setup: resident rows, zeroed accumulators
-    float ain[6];                                                   // per thread: q_a | p_j, a_prev_j, dalign_j | two direct dctx sources
+    // LSA (attention.py:26-85) geometry and buffers
+    const int F = d.F, Kc = d.Kc, F1 = F + 1, pad = (Kc - 1) / 2, TwP = M.TwP, UP = A + 4, WN = len + 2 * pad;
+    float* wL = smem + M.ps;                                         // softmax weights of the step (own positions)
+    float* ccL = smem + M.cc; float* convwL = smem + M.convw; float* dlocL = smem + M.dloc; float* wpadL = smem + M.wpad;
+    float* utL = smem + M.scratch + M.ut; float* locL = smem + M.scratch + M.loc; float* lredL = smem + M.scratch + M.red;
+    (void)F1; (void)TwP; (void)UP; (void)WN; (void)wL; (void)ccL; (void)convwL; (void)dlocL; (void)wpadL; (void)utL; (void)locL; (void)lredL;
+    const int ljt = wave >> 2, lat = wave & 3;                       // LSA: this wave's (position tile, channel tile) of the [len x A] tile
+    f32x16 accWd, accWc;                                             // LSA: d(Wd) tile of waves 2..5, d(Wc) tile of waves 2..3, summed over all steps
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { accWd[e] = 0.f; accWc[e] = 0.f; }
+    float ain[6];                                                   // per thread: q_a | p_j (LSA: w_j), a_prev_j (LSA: [w; cum](t-1) with halos), dalign_j | two direct dctx sources
     auto load_ain = [&](int t, int tid) {
         const long rb = (long)t * B + ab_;
         ain[0] = tid < A ? AS.qs[rb * A + tid] : 0.f;
         const int j = jb + tid;
         const bool in = tid < ng;
-        ain[1] = (in && tid < len) ? AS.psel[((long)ab_ * d.T + t) * Tin + j] : 0.f;
-        ain[2] = (in && tid < len) ? (t > 0 ? AS.align[((long)ab_ * d.T + t - 1) * Tin + j] : (j == 0 ? 1.f : 0.f)) : 0.f;
+        if constexpr (KIND == CHAIN_LSA) {
+            ain[1] = tid < len ? AS.align[((long)ab_ * d.T + t) * Tin + j] : 0.f;
+            // [w_{t-1}; cum_{t-1}] at positions jb - pad .. je + pad - 1 (zero outside the memory and at t = 0)
+            const int c = tid / WN, x = tid - c * WN, jw = jb - pad + x;
+            ain[2] = (tid < 2 * WN && t > 0 && jw >= 0 && jw < Tin) ? (c == 0 ? AS.align : AS.wcum)[((long)ab_ * d.T + t - 1) * Tin + jw] : 0.f;
+        } else {
+            ain[1] = (in && tid < len) ? AS.psel[((long)ab_ * d.T + t) * Tin + j] : 0.f;
+            ain[2] = (in && tid < len) ? (t > 0 ? AS.align[((long)ab_ * d.T + t - 1) * Tin + j] : (j == 0 ? 1.f : 0.f)) : 0.f;
+        }
         ain[3] = (in && AS.dalign) ? AS.dalign[((long)ab_ * d.T + t) * Tin + j] : 0.f;
         ain[4] = tid < E ? AS.dctx_a[rb * AS.lddctx_a + tid] : 0.f;
         ain[5] = tid < E ? AS.dctx_b[rb * AS.lddctx_b + tid] : 0.f;
@@ -336,7 +364,8 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
         for (int a = tid; a < A; a += NTH) { vL[a] = AS.v[a]; dvaL[a] = 0.f; }
         for (int i = tid; i < len * (A / 4); i += NTH) {
             const int jl = i / (A / 4), a4 = (i % (A / 4)) * 4;
-            *reinterpret_cast<f32x4*>(pmL + jl * A + a4) = *reinterpret_cast<const f32x4*>(AS.pm + ((long)ab_ * Tin + jb + jl) * A + a4);
+            if constexpr (KIND == CHAIN_SMA)
+                *reinterpret_cast<f32x4*>(pmL + jl * A + a4) = *reinterpret_cast<const f32x4*>(AS.pm + ((long)ab_ * Tin + jb + jl) * A + a4);
             *reinterpret_cast<f32x4*>(dpmL + jl * A + a4) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         for (int i = tid; i < ng * (E / 4); i += NTH) {
@@ -346,6 +375,12 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
             *reinterpret_cast<bf16x4*>(memL + jl * E + c4) = o;
         }
         for (int j = tid; j < chunk + 8; j += NTH) carryL[j] = 0.f;
+        if constexpr (KIND == CHAIN_LSA) {
+            for (int j = tid; j < chunk + 8; j += NTH) ccL[j] = 0.f;
+            for (int i = tid; i < F * 2 * Kc; i += NTH) convwL[i] = AS.loc_conv[i];
+            for (int i = tid; i < (d.lds_Tc + 2 * pad) * F1; i += NTH) dlocL[i] = 0.f;
+            for (int i = tid; i < 4 * TwP; i += NTH) wpadL[i] = 0.f;
+        }
         load_ain(d.t1 - 1, tid);
     }
     __syncthreads();
@@ -362,6 +397,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
         asm volatile("" : "+v"(tv));
         // ======================================================================================= A(t)
         if (hasA) {
+            if constexpr (KIND == CHAIN_SMA) {
             const int tid = tv, lane = tid & 63, wave = tid >> 6;
             T2_BSTAMP(15);
             float in[6];
@@ -481,6 +517,294 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
             T2_BSTAMP(4);
             if (tid < A) AS.dq_out[((long)t * B + ab_) * 2 * A + split * A + tid] = dqoL[tid];
             if (t > d.t0) load_ain(t - 1, tid);
+                    } else {
+            const int tid = tv, lane = tid & 63, wave = tid >> 6, r = lane & 31, hk = lane >> 5;
+            T2_BSTAMP(15);
+            float in[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) in[i] = ain[i];
+            float* wnew = wpadL + (t & 1) * 2 * TwP;                     // [w_{t-1}; cum_{t-1}] of THIS step, halos included
+            const float* wold = wpadL + ((t + 1) & 1) * 2 * TwP;         // ... of step t+1 (whose dloc is in dlocL)
+            const int njt = (len + 31) / 32;
+            float wdf[16];                                               // Wd[lat*32 + r][2i + hk]: B operand of the pa product (L2-resident; requested here, used below)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { const int f = 2 * i + hk; wdf[i] = f < F ? AS.loc_dense[(long)(lat * 32 + r) * F + f] : 0.f; }
+            // ------------------------------------------------------------------------------------------------------------
+            // In front of the poll (none of it needs the context gradient of this step): halo rows of dloc(t+1) from the
+            // other split, gradient carried to w_t / cum_t, d(Wc) of step t+1, location features and tanh tile of step t.
+            // ------------------------------------------------------------------------------------------------------------
+            if (ep > 0) {
+                if (wave == 0 && !poll_counter(CNT(4 + as * 2 + ab_ / 32), ep * (unsigned)(min(32, B - (ab_ / 32) * 32) * 2), d.err, 11u) && lane == 0) *abortw = 1;
+                __syncthreads();
+                if (*abortw) return;
+                if (tid < pad * (F / 4)) {                                // the partner's `pad` rows next to the boundary
+                    const int row = tid / (F / 4), f4 = (tid % (F / 4)) * 4;
+                    const unsigned off = (unsigned)((((((t + 1) & 1) * d.NS + as) * B + ab_) * 2 + (1 - split)) * pad * F + row * F + f4) * 4u;
+                    const f32x4 h4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, off, 0, SC1));
+                    float* dst = dlocL + (split == 0 ? len + pad + row : row) * F1 + f4;
+                    if ((split == 0 && je < Tin) || (split == 1 && jb > 0)) { dst[0] = h4[0]; dst[1] = h4[1]; dst[2] = h4[2]; dst[3] = h4[3]; }
+                }
+            }
+            if (tid < A) qL[tid] = in[0];
+            if (tid < len) wL[tid] = in[1];
+            if (tid < 2 * WN) { const int c = tid / WN; wnew[c * TwP + (tid - c * WN)] = in[2]; }
+            __syncthreads();
+            if (wave < njt) {
+                // loc[j][f] = sum_{c,k} Wc[f][c][k] wcat[c][j + k - pad]: Toeplitz product on the matrix cores (exact fp32 fma chains)
+                const float* xr = wnew + min(wave * 32 + r, len - 1);
+                const float* wr = convwL + min(r, F - 1) * 2 * Kc;
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                for (int kk = 0; kk < 2 * Kc; kk += 2) {
+                    const int ck = kk + hk, c = ck >= Kc ? 1 : 0, k = ck - c * Kc;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[c * TwP + k], wr[ck], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int jl = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk;
+                    if (jl < len && r < F) locL[jl * F1 + r] = acc[e];
+                }
+                if (hk == 0 && wave * 32 + r < len) locL[(wave * 32 + r) * F1 + F] = 0.f;      // pad column (K of the products below is even)
+            } else if (wave < 4) {
+                if (ep > 0 && wave >= 2 && wave - 2 < (2 * Kc + 31) / 32) {
+                    // d(Wc)[f][(c,k)] += sum_j dloc(t+1)[j][f] wcat(t+1)[c][j + k - pad]   (rows f, columns (c,k), K = own positions)
+                    const int n = min((wave - 2) * 32 + r, 2 * Kc - 1), c = n / Kc, k = n - c * Kc;
+                    const float* ar = dlocL + (pad + hk) * F1 + min(r, F);
+                    const float* br = wold + c * TwP + k + hk;
+                    const int le = (len + 1) & ~1;
+                    for (int kk = 0; kk < le; kk += 2) {
+                        const bool ok = kk + hk < len;
+                        accWc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? ar[kk * F1] : 0.f, ok ? br[kk] : 0.f, accWc, 0, 0, 0);
+                    }
+                }
+            } else if (ep > 0) {
+                // gradient on [w_t; cum_t] through the location conv of step t+1:
+                // dwcat[c][i] = sum_{f,k} Wc[f][c][k] dloc[i - k + pad][f]; work item (f group of 8, c, 4 positions), window sliding downwards
+                const int t0 = tid - 256, ni4 = (len + 3) / 4, Tp4 = ni4 * 4;
+                float* tmp = lredL;                                       // [8][2][Tp4]
+                if (t0 < 8 * 2 * ni4) {
+                    const int fq = t0 / (2 * ni4), c = (t0 / ni4) % 2, i0 = (t0 % ni4) * 4;
+                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                    for (int f = fq; f < F; f += 8) {
+                        const float* w = convwL + (f * 2 + c) * Kc;
+                        const float* dl = dlocL + (i0 + 2 * pad) * F1 + f;    // row of position i0 - k + pad at k = 0
+                        float d3 = dl[3 * F1], d2 = dl[2 * F1], d1 = dl[F1];
+                        for (int k = 0; k < Kc; ++k) {
+                            const float d0 = dl[-k * F1], wk = w[k];
+                            s0 += wk * d0; s1 += wk * d1; s2 += wk * d2; s3 += wk * d3;
+                            d3 = d2; d2 = d1; d1 = d0;
+                        }
+                    }
+                    float* tp = tmp + (fq * 2 + c) * Tp4 + i0;
+                    tp[0] = s0; tp[1] = s1; tp[2] = s2; tp[3] = s3;
+                }
+            }
+            __syncthreads();
+            if (ep > 0 && tid < 2 * len) {
+                const int c = tid / len, i = tid - c * len, Tp4 = ((len + 3) / 4) * 4;
+                float sum = 0.f;
+#pragma unroll
+                for (int fq = 0; fq < 8; ++fq) sum += lredL[(fq * 2 + c) * Tp4 + i];
+                if (c == 0) carryL[i] = sum; else ccL[i] += sum;
+            }
+            // pa = loc . Wd^T for this wave's [32 positions x 32 channels] tile, then u = tanh(q + pm + pa) into the tile
+            if (ljt < njt) {
+                const float* lr = locL + min(ljt * 32 + r, len - 1) * F1 + hk;
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (2 * i < ((F + 1) & ~1)) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lr[2 * i], wdf[i], acc, 0, 0, 0);
+                const int a = lat * 32 + r;
+                const float qa = qL[a];
+                const float* pmr = AS.pm + ((long)ab_ * Tin + jb) * A + a;
+                float pv[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int jl = min(ljt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk, len - 1);
+                    pv[e] = pmr[(long)jl * A];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int jl = ljt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk;
+                    if (jl < len) utL[jl * UP + a] = fast_tanh(qa + pv[e] + acc[e]);
+                }
+            }
+            // ------------------------------------------------------------------------------------------------------------
+            if (ep > 0) {
+                if (wave == 0 && !poll_counter(CNT(2 + as), ep * (unsigned)(NTC * AKP), d.err, 7u) && lane == 0) *abortw = 1;
+                __syncthreads();
+                if (*abortw) return;
+            } else __syncthreads();
+            T2_BSTAMP(0);
+            bf16x8 wdt[8];                                               // Wd^T fragments (column f = r, channels 16i + 8hk ..) of the dloc product: waves 0..1
+            if (wave < njt) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wdt[i] = *reinterpret_cast<const bf16x8*>(AS.wdt16 + (long)min(r, F - 1) * A + 16 * i + 8 * hk);
+            }
+            if (tid < E) {
+                float v = in[4] + in[5];
+                if (ep > 0) {
+                    const unsigned off = (unsigned)((t + 1) & 1) * pbc_half + (unsigned)as * pbc_s + (unsigned)((ab_ * E + tid) * 4);
+                    float pv[AKP];
+#pragma unroll
+                    for (int z = 0; z < AKP; ++z) pv[z] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsC, off + z * pbc_kp, 0, SC1));
+                    v += (pv[0] + pv[1]) + (pv[2] + pv[3]);
+                }
+                dctxL[tid] = v;
+                if (split == 0) AS.dctx_out[((long)t * B + ab_) * E + tid] = v;
+            }
+            __syncthreads();
+            T2_BSTAMP(1);
+            // g_j = dctx . memory_j + dalign_j + carried gradients (own positions)
+            for (int jl = wave; jl < len; jl += NWV) {
+                float sum = 0.f;
+                for (int c = lane * 8; c < E; c += 512) {
+                    const bf16x8 mb = *reinterpret_cast<const bf16x8*>(memL + jl * E + c);
+                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(dctxL + c), d1 = *reinterpret_cast<const f32x4*>(dctxL + c + 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sum += (float)mb[k] * d0[k] + (float)mb[4 + k] * d1[k];
+                }
+                sum = wave_sum(sum);
+                if (lane == 0) gL[jl] = sum;
+            }
+            __syncthreads();
+            float part = 0.f;
+            if (tid < len) {
+                float gsum = gL[tid] + in[3];
+                if (ep > 0) gsum += carryL[tid] + ccL[tid];
+                gL[tid] = gsum;
+                part = wL[tid] * gsum;
+            }
+            // softmax backward needs S = sum_j w_j g_j over BOTH splits: each publishes its partial (value + step tag, one
+            // write-through store) and reads the partner's
+            part = wave_sum(part);
+            if (lane == 0) lredL[wave] = part;
+            __syncthreads();
+            if (wave == 0) {
+                float mine = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWV; ++w) mine += lredL[w];
+                const unsigned sbase = (unsigned)(pad * F * 2 * d.NS * B * 2) * 4u;                 // behind the halo rows
+                const unsigned soff = sbase + (unsigned)((((t & 1) * d.NS + as) * B + ab_) * 2) * 8u;
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                if (lane == 0) {
+                    u32x2 o; o[0] = __builtin_bit_cast(unsigned, mine); o[1] = (unsigned)(t + 1);
+                    __builtin_amdgcn_raw_buffer_store_b64(o, rsK, soff + (unsigned)split * 8u, 0, SC1);
+                }
+                float other = 0.f;
+                if (len < Tin) {                                          // (a memory short enough for one split has no partner)
+                    const unsigned long long t0c = __builtin_amdgcn_s_memrealtime();
+                    for (;;) {
+                        const u32x2 v2 = __builtin_amdgcn_raw_buffer_load_b64(rsK, soff + (unsigned)(1 - split) * 8u, 0, SC1);
+                        if (v2[1] == (unsigned)(t + 1)) { other = __builtin_bit_cast(float, v2[0]); break; }
+                        if (__builtin_amdgcn_s_memrealtime() - t0c > SPIN_TICKS) { if (lane == 0) { atomicMax(d.err, 12u); *abortw = 1; } break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                if (lane == 0) lredL[NWV] = split == 0 ? mine + other : other + mine;          // same order in both splits
+            }
+            __syncthreads();
+            if (*abortw) return;
+            const float sdot = lredL[NWV];
+            if (tid < len) deL[tid] = wL[tid] * (gL[tid] - sdot);
+            __syncthreads();
+            T2_BSTAMP(2);
+            // energies backward on the tanh tile: dpre = de_j v_a (1 - u^2) replaces u in place; d(pm), dq, dv
+            {
+                const int gid = tid >> 4, sub = tid & 15;
+                f32x4 dq[2], dv[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { dq[k] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                for (int jl = gid; jl < len; jl += NTH / 16) {
+                    const float dej = deL[jl];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int a = sub * 4 + 64 * k;
+                        const f32x4 u4 = *reinterpret_cast<const f32x4*>(utL + jl * UP + a);
+                        f32x4 acc = *reinterpret_cast<const f32x4*>(dpmL + jl * A + a);
+                        f32x4 dp;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float dpre = dej * vL[a + c] * (1.0f - u4[c] * u4[c]);
+                            dq[k][c] += dpre; dv[k][c] += dej * u4[c]; acc[c] += dpre; dp[c] = dpre;
+                        }
+                        *reinterpret_cast<f32x4*>(dpmL + jl * A + a) = acc;
+                        *reinterpret_cast<f32x4*>(utL + jl * UP + a) = dp;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        dq[k][c] += __shfl_xor(dq[k][c], 16, 64); dq[k][c] += __shfl_xor(dq[k][c], 32, 64);
+                        dv[k][c] += __shfl_xor(dv[k][c], 16, 64); dv[k][c] += __shfl_xor(dv[k][c], 32, 64);
+                    }
+                if (lane < 16) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        *reinterpret_cast<f32x4*>(lredL + wave * A + sub * 4 + 64 * k) = dq[k];
+                        *reinterpret_cast<f32x4*>(lredL + (NWV + wave) * A + sub * 4 + 64 * k) = dv[k];
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < A) {
+                float sq = 0.f, sv = 0.f;
+#pragma unroll
+                for (int k = 0; k < NWV; ++k) { sq += lredL[k * A + tid]; sv += lredL[(NWV + k) * A + tid]; }
+                dqoL[tid] = sq;
+                dvaL[tid] += sv;
+            }
+            // dloc[j][f] = sum_a dpre[j][a] Wd[a][f] (waves 0..1, bf16 operands as every large product of this mode) and
+            // d(Wd)[a][f] += sum_j dpre[j][a] loc[j][f] (waves 2..5, exact fp32), both straight off the tile
+            if (wave < njt) {
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                const float* ur = utL + min(wave * 32 + r, len - 1) * UP + 8 * hk;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(ur + 16 * i), hi = *reinterpret_cast<const f32x4*>(ur + 16 * i + 4);
+                    bf16x8 af;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { af[c] = (__bf16)lo[c]; af[4 + c] = (__bf16)hi[c]; }
+                    if (16 * i < A) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wdt[i], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int jl = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk;
+                    if (jl < len && r < F) dlocL[(pad + jl) * F1 + r] = acc[e];
+                }
+            } else if (wave >= 2 && wave < 6) {
+                const float* ar = utL + hk * UP + (wave - 2) * 32 + r;
+                const float* br = locL + hk * F1 + min(r, F);
+                const int le = (len + 1) & ~1;
+                for (int kk = 0; kk < le; kk += 2) {
+                    const bool ok = kk + hk < len;
+                    accWd = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? ar[kk * UP] : 0.f, ok ? br[kk * F1] : 0.f, accWd, 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            // hand-offs: dq partial of this split, the `pad` rows of dloc next to the boundary
+            if (tid < A / 4) {
+                const f32x4 q4 = *reinterpret_cast<const f32x4*>(dqoL + tid * 4);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q4), rsQ, (unsigned)((((as * 2 + split) * B + ab_) * A + tid * 4) * 4), 0, SC1);
+            } else if (tid >= 64 && tid < 64 + pad * (F / 4)) {
+                const int i = tid - 64, row = i / (F / 4), f4 = (i % (F / 4)) * 4;
+                const float* src = dlocL + (pad + (split == 0 ? len - pad + row : row)) * F1 + f4;
+                const f32x4 h4 = {src[0], src[1], src[2], src[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h4), rsK,
+                    (unsigned)(((((t & 1) * d.NS + as) * B + ab_) * 2 + split) * pad * F + row * F + f4) * 4u, 0, SC1);
+            }
+            T2_BSTAMP(3);
+            publish(CNT(4 + as * 2 + ab_ / 32));
+            T2_BSTAMP(4);
+            if (tid < A) AS.dq_out[((long)t * B + ab_) * 2 * A + split * A + tid] = dqoL[tid];
+            if (t > d.t0) load_ain(t - 1, tid);
+            }
         }
         // ======================================================================================= P(t)
         if (hasP) {
@@ -572,21 +896,31 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
             if (*abortw) return;
             T2_BSTAMP(8);
             const unsigned xb = (unsigned)((t & 1) * d.NS + gs) * xs + (unsigned)lane * 16u;
-            u32x4 af[MT][8];
+            // (LSA keeps two MFMA accumulators of weight gradients in registers for all steps: its row tiles' fragments are
+            // requested one tile at a time)
+            constexpr bool SEQ_M = KIND == CHAIN_LSA && MT > 1;
+            u32x4 af[SEQ_M ? 1 : MT][8];
+            if constexpr (!SEQ_M) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    af[m][i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xb + (unsigned)(((kp * (H / 16) + wave * 8 + i) * MT + m) * 1024), 0, SC1);
+                    for (int i = 0; i < 8; ++i)
+                        af[m][i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xb + (unsigned)(((kp * (H / 16) + wave * 8 + i) * MT + m) * 1024), 0, SC1);
+            }
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m) {
+                if constexpr (SEQ_M) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        af[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xb + (unsigned)(((kp * (H / 16) + wave * 8 + i) * MT + m) * 1024), 0, SC1);
+                }
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     f32x16 acc;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[m][i]), W[c][i], acc, 0, 0, 0);
+                    for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[SEQ_M ? 0 : m][i]), W[c][i], acc, 0, 0, 0);
                     if (m + c > 0) __syncthreads();
 #pragma unroll
                     for (int e = 0; e < 16; ++e) partL[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk) * PPR + r] = acc[e];
@@ -610,6 +944,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
                         }
                     }
                 }
+            }
             T2_BSTAMP(9);
             publish(nt < NTC ? CNT(2 + gs) : CNT(8 + gs * 16 + (nt - NTC)));
             T2_BSTAMP(10);
@@ -621,6 +956,24 @@ __global__ __launch_bounds__(NTH) void chain_bwd_sma_kernel(ChainBwdDesc d) {
 #endif
     // ---------------------------------------------------------------- A epilogue: the accumulators leave LDS
     if (hasA) {
+        if constexpr (KIND == CHAIN_LSA) {
+            // location-layer weight gradients of this (split, item): the MFMA accumulators of waves 2..5 / 2..3
+            if (wave >= 2 && wave < 6 && r < F) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int a = (wave - 2) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk;
+                    AS.ddense_acc[(((long)split * B + ab_) * A + a) * F + r] = accWd[e];
+                }
+            }
+            const int n = (wave - 2) * 32 + r;
+            if (wave >= 2 && wave < 4 && n < 2 * Kc) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int f = (e & 3) + 8 * (e >> 2) + 4 * hk;
+                    if (f < F) AS.dconv_acc[(((long)split * B + ab_) * F + f) * 2 * Kc + n] = accWc[e];
+                }
+            }
+        }
         for (int a = tid; a < A; a += NTH) AS.dv_acc[((long)split * B + ab_) * A + a] = dvaL[a];
         for (int i = tid; i < len * (A / 4); i += NTH) {
             const int jl = i / (A / 4), a4 = (i % (A / 4)) * 4;
@@ -635,14 +988,20 @@ bool chain_bwd_plan(ChainBwdDesc& d) {
     if (d.H != 1024 || d.B < 1 || d.B > 64) return false;
     if (chain_device_cus() < 256) return false;
     if (d.kind == CHAIN_LSTM) return true;
-    if (d.kind != CHAIN_SMA || d.E != 512 || d.A != 128 || d.NS < 1 || d.NS > 2) return false;
+    if ((d.kind != CHAIN_SMA && d.kind != CHAIN_LSA) || d.E != 512 || d.A != 128 || d.NS < 1 || d.NS > 2) return false;
+    const bool lsa = d.kind == CHAIN_LSA;
+    if (lsa && (d.F < 4 || d.F > 32 || d.F % 4 != 0 || d.Kc < 3 || d.Kc > 31 || d.Kc % 2 == 0)) return false;
+    const int pad = lsa ? (d.Kc - 1) / 2 : 0;
     int tc = 0;
     for (int s = 0; s < d.NS; ++s) {
-        if (d.st[s].Tin < 16) return false;                          // (two position splits per item, as the launch path at these sizes)
-        tc = std::max(tc, (((d.st[s].Tin + 1) / 2) + 3) & ~3);
+        const int Tin = d.st[s].Tin, chunk = (((Tin + 1) / 2) + 3) & ~3;
+        if (Tin < 16) return false;                                  // (two position splits per item, as the launch path at these sizes)
+        // LSA: both splits hold at least the `pad` rows they hand to each other; one [positions x A] tile row pair per wave
+        if (lsa && (Tin - chunk < pad || chunk < pad || chunk > 64)) return false;
+        tc = std::max(tc, chunk);
     }
     d.lds_Tc = tc;
-    return (size_t)bwd_lds_of(d.A, d.E, tc, (d.B + 31) / 32).total * sizeof(float) <= 160 * 1024;
+    return (size_t)bwd_lds_of(d.A, d.E, tc, (d.B + 31) / 32, d.kind, d.F, d.Kc).total * sizeof(float) <= 160 * 1024;
 }
 
 size_t chain_bwd_exchange_bytes(const ChainBwdDesc& d, size_t* x_bytes, size_t* pb_bytes) {
@@ -652,6 +1011,10 @@ size_t chain_bwd_exchange_bytes(const ChainBwdDesc& d, size_t* x_bytes, size_t* 
     return *x_bytes + *pb_bytes;
 }
 
+size_t chain_bwd_lsa_tagged_bytes(const ChainBwdDesc& d) {
+    return ((size_t)(((d.Kc - 1) / 2) * d.F + 2) * 2 * d.NS * d.B * 2 * sizeof(float) + 255) & ~(size_t)255;
+}
+
 size_t chain_bwd_att_exchange_bytes(const ChainBwdDesc& d, size_t* x_bytes, size_t* pbh_bytes, size_t* pbc_bytes, size_t* dqx_bytes, size_t* carry_bytes) {
     const size_t MT = (d.B + 31) / 32, al = 255;
     *x_bytes = (size_t)2 * d.NS * (4 * d.H / 16) * MT * 1024;
@@ -659,6 +1022,8 @@ size_t chain_bwd_att_exchange_bytes(const ChainBwdDesc& d, size_t* x_bytes, size
     *pbc_bytes = ((size_t)2 * d.NS * AKP * d.B * d.E * sizeof(float) + al) & ~al;
     *dqx_bytes = ((size_t)d.NS * 2 * d.B * d.A * sizeof(float) + al) & ~al;
     *carry_bytes = ((size_t)2 * d.NS * d.B * sizeof(float) + al) & ~al;
+    if (d.kind == CHAIN_LSA)      // halo rows + softmax-dot slots (cleared per launch), then the bf16 Wd^T copies [NS][F][A]
+        *carry_bytes = chain_bwd_lsa_tagged_bytes(d) + (((size_t)d.NS * d.F * d.A * sizeof(__bf16) + al) & ~al);
     return *x_bytes + *pbh_bytes + *pbc_bytes + *dqx_bytes + *carry_bytes;
 }
 
@@ -667,18 +1032,23 @@ int chain_bwd(const ChainBwdDesc& d, hipStream_t s) {
     T2_REQUIRE(d.X && d.PB && d.cnt && d.err, "chain_bwd: exchange buffers missing");
     const int MT = (d.B + 31) / 32;
     T2_CHECK_HIP(hipMemsetAsync(d.cnt, 0, kChainBwdCntBytes, s));
-    if (d.kind == CHAIN_SMA) {
+    if (d.kind == CHAIN_SMA || d.kind == CHAIN_LSA) {
         T2_REQUIRE(d.t0 == 0 && d.t1 == d.T, "chain_bwd: the attention chain runs its whole step range in one launch");
         T2_REQUIRE(d.PBC && d.DQX && d.CARRYX, "chain_bwd: exchange buffers missing");
-        const size_t smem = (size_t)bwd_lds_of(d.A, d.E, d.lds_Tc, MT).total * sizeof(float);
+        const size_t smem = (size_t)bwd_lds_of(d.A, d.E, d.lds_Tc, MT, d.kind, d.F, d.Kc).total * sizeof(float);
         const int grid = std::max(std::max(d.NS * (d.E + d.H) / ANC * AKP, d.NS * (d.H / PU) * MT), d.NS * d.B * 2);
-        if (MT == 1) {
-            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_bwd_sma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL(chain_bwd_sma_kernel<1>, dim3(grid), dim3(NTH), smem, s, d);
-        } else {
-            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_bwd_sma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL(chain_bwd_sma_kernel<2>, dim3(grid), dim3(NTH), smem, s, d);
+        if (d.kind == CHAIN_LSA) {                                   // the softmax-dot slots carry step tags: clear them
+            T2_CHECK_HIP(hipMemsetAsync(d.CARRYX, 0, chain_bwd_lsa_tagged_bytes(d), s));
         }
+        auto launch = [&](auto kernel) -> int {
+            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(NTH), smem, s, d);
+            return 0;
+        };
+        int rc;
+        if (d.kind == CHAIN_SMA) rc = MT == 1 ? launch(chain_bwd_att_kernel<1, CHAIN_SMA>) : launch(chain_bwd_att_kernel<2, CHAIN_SMA>);
+        else rc = MT == 1 ? launch(chain_bwd_att_kernel<1, CHAIN_LSA>) : launch(chain_bwd_att_kernel<2, CHAIN_LSA>);
+        if (rc) return rc;
         T2_LAUNCH_CHECK();
         return 0;
     }

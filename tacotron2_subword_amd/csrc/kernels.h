@@ -252,18 +252,24 @@ struct ChainBwdStream {
     float* dq_out;                        // [T][B][2A] one partial per position split (dWq GEMM)
     float* dv_acc;                        // [2][B][A]
     float* dpm_acc;                       // [B][Tin][A]
+    // CHAIN_LSA (attention.py:26-85): saved cumulative weights, location-layer weights, per-(split, item) accumulators
+    const float* wcum;                    // [B,T,Tin]
+    const float* loc_conv; const float* loc_dense;   // [F][2][Kc], [A][F]
+    float* dconv_acc; float* ddense_acc;  // [2][B][F][2Kc], [2][B][A][F]
+    const __bf16* wdt16;                  // [F][A] bf16 transpose of loc_dense (made by the caller in the exchange area)
 };
 struct ChainBwdDesc {
     ChainBwdStream st[2]; int NS, B, T, t0, t1, H, kind;
-    int E, A;
+    int E, A, F, Kc;
     float drop_p; uint64_t seed;
     unsigned char* X; unsigned char* PB; unsigned* cnt; unsigned* err; unsigned pb_bytes;   // exchange: dg fragments, K-split partials
-    unsigned char* PBC; unsigned pbc_bytes; float* DQX; float* CARRYX;                       // attention chain: ctx partials, dq partials, boundary carry
+    unsigned char* PBC; unsigned pbc_bytes; float* DQX; float* CARRYX;                       // attention chain: ctx partials, dq partials, boundary carry (LSA: halo rows of dloc + softmax-dot partials)
     int lds_Tc;                                                                              // positions per split of the longest memory (LDS carve)
 };
 constexpr size_t kChainBwdCntBytes = 64 * 128;     // arrival counters, one per 128-byte line
 bool chain_bwd_plan(ChainBwdDesc& d);
 size_t chain_bwd_exchange_bytes(const ChainBwdDesc& d, size_t* x_bytes, size_t* pb_bytes);
+size_t chain_bwd_lsa_tagged_bytes(const ChainBwdDesc& d);   // LSA: leading part of the carry area (halo rows, tagged softmax-dot slots)
 size_t chain_bwd_att_exchange_bytes(const ChainBwdDesc& d, size_t* x_bytes, size_t* pbh_bytes, size_t* pbc_bytes, size_t* dqx_bytes, size_t* carry_bytes);
 int chain_bwd(const ChainBwdDesc& d, hipStream_t s);
 

@@ -109,22 +109,29 @@ def test_chain_long_sequence_stays_close_to_fp32(env):
     assert errs["mel"] < 0.08 and errs["gate"] < 0.05 and errs["align"] < 0.02 and errs["align_sub"] < 0.02, errs
 
 
-def test_backward_chain_matches_per_step_backward(env):
-    """Same forward (persistent chains), backward of the decoder LSTM as one persistent launch per step range vs one
-    launch per step and kernel: the two differ in summation order only (same bf16 operands, same RNG keys)."""
+@pytest.mark.parametrize("att", [SMA, LSA])
+def test_backward_chain_matches_per_step_backward(env, att):
+    """Same forward (persistent chains), backward as persistent launches vs one launch per step and kernel: the two differ
+    in summation order only (same bf16 operands, same RNG keys; LSA: the dloc product takes bf16 operands in the chain).
+    LSA memories are long enough for two position splits with 15-row halos (the persistent LSA backward's geometry);
+    the profile counters show that the persistent kernel really ran."""
     L, ops = env
     res = {}
-    for B, T in ((8, 10), (64, 40)):                      # T = 40: several step ranges (the chunked two-stream schedule)
+    cases = ((8, 10, 40, 36), (64, 40 if att is SMA else 24, 100, 60))
+    for B, T, Tin, Tsub in cases:
         for bwd in (False, True):
             L.set_chain_bwd(bwd)
             try:
-                out, st, (W, P, dims, dp, mem, mems) = _run(env, SMA, B, 21, 12, T, chain=True, training=True)
+                out, st, (W, P, dims, dp, mem, mems) = _run(env, att, B, Tin, Tsub, T, chain=True, training=True)
                 g = torch.Generator(device="cuda").manual_seed(3)
                 dmel = torch.randn(B, T, 80, device="cuda", generator=g)
                 dgate = torch.randn(B, T, device="cuda", generator=g)
+                L.prof_enable(8 * T + 64)
                 G, dm, dms = ops.decoder_backward(W, P, dims, dp, mem, mems, dmel, dgate, training=True, prenet_dropout=True, seed=11)
                 torch.cuda.synchronize()
+                prof = L.prof_collect()
                 assert not any(dp.chain_status()), dp.chain_status()
+                assert prof["chain_a_bwd"][1] == (1 if bwd else 0), prof
             finally:
                 L.set_chain_bwd(True)
             res[bwd] = dict(G, d_memory=dm, d_memory_sub=dms)
@@ -132,7 +139,7 @@ def test_backward_chain_matches_per_step_backward(env):
         for k, v in res[False].items():
             if v is not None:
                 worst[k] = float((res[True][k] - v).norm()) / (float(v.norm()) + 1e-12)
-        print(f"B={B} T={T}: relative gradient deviation, persistent vs per-step backward:", dict(sorted(worst.items(), key=lambda kv: -kv[1])[:4]))
+        print(f"{att} B={B} T={T}: relative gradient deviation, persistent vs per-step backward:", dict(sorted(worst.items(), key=lambda kv: -kv[1])[:4]))
         assert max(worst.values()) < 5e-3, worst
 
 
