@@ -11,15 +11,16 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from oracle import recipe
-from helpers import hp_for, to_dev, SMA
+from helpers import hp_for, to_dev, SMA, LSA
 from tacotron2_subword_amd import _lib as L, ops
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=64)
 ap.add_argument("--T", type=int, default=400)
+ap.add_argument("--att", default="sma")
 a = ap.parse_args()
 L.set_precision("bf16")
-hp = hp_for(SMA)
+hp = hp_for(SMA if a.att == "sma" else LSA)
 P = to_dev(recipe.make_weights(hp))
 dims = L.dims_from_hparams(hp)
 W = L.decoder_weights(P, dims.attention_kind)
@@ -33,7 +34,7 @@ dmel = torch.randn(a.B, a.T, 80, device="cuda", generator=g)
 dgate = torch.randn(a.B, a.T, device="cuda", generator=g)
 lib = L.lib()
 NAMES = ["A wait ctx partials", "A dctx + operands", "A g / recurrence", "A energies bwd + dq", "A publish", "P wait dq / h partials",
-         "P dq.Wq + gates + frags", "P publish", "G wait dg", "G loads + MFMA + reduce + stores", "G publish", "-", "-", "-", "-",
+         "P dq.Wq + gates + frags", "P publish", "G wait dg", "G loads + MFMA + reduce + stores", "G publish", "LSA: halo rows + operands -> LDS", "LSA: loc conv | dWc | carried gradients", "LSA: pa + tanh tile", "-",
          "(G publish -> next A start: stores, prefetch)"]
 for it in range(2):
     dp = ops.decoder_forward(W, dims, mem, mems, tl, bl, mels, training=True, prenet_dropout=True, seed=it)

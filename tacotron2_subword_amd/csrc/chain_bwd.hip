@@ -247,7 +247,9 @@ __host__ __device__ inline BwdLds bwd_lds_of(int A, int E, int Tc, int MT, int k
     m.cc = take(lsa ? Tc + 8 : 0); m.convw = take(lsa ? F * 2 * Kc : 0); m.dloc = take(lsa ? (Tc + 2 * pad) * (F + 1) : 0);
     m.wpad = take(lsa ? 4 * m.TwP : 0);
     // scratch shared by the phases; LSA's A phase: tanh / dpre tile [Tc][A + 4], location features [Tc][F + 1], reduction rows
-    m.ut = 0; m.loc = (Tc * (A + 4) + 3) & ~3; m.red = m.loc + ((Tc * (F + 1) + 3) & ~3);
+    // (the tile's room first holds Q = dloc . Wc^T, [Tc + 2 pad][65], of the carried-gradient step)
+    const int nut = Tc * (A + 4), nq = (Tc + 2 * pad) * 65;
+    m.ut = 0; m.loc = ((nut > nq ? nut : nq) + 3) & ~3; m.red = m.loc + ((Tc * (F + 1) + 3) & ~3);
     const int sg = NWV * 32 * PPR, sp = 32 * (A + 4) + 4 * 32 * (PU + 4), sa = lsa ? m.red + 2 * NWV * A : 2 * 32 * A;
     m.scratch = take(sg > sp ? (sg > sa ? sg : sa) : (sp > sa ? sp : sa));
     m.total = o;
@@ -338,7 +340,24 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
     float* utL = smem + M.scratch + M.ut; float* locL = smem + M.scratch + M.loc; float* lredL = smem + M.scratch + M.red;
     (void)F1; (void)TwP; (void)UP; (void)WN; (void)wL; (void)ccL; (void)convwL; (void)dlocL; (void)wpadL; (void)utL; (void)locL; (void)lredL;
     const int ljt = wave >> 2, lat = wave & 3;                       // LSA: this wave's (position tile, channel tile) of the [len x A] tile
-    f32x16 accWd, accWc;                                             // LSA: d(Wd) tile of waves 2..5, d(Wc) tile of waves 2..3, summed over all steps
+    // n chained fp32 MFMAs whose operands come from LDS: requested 8 pairs at a time, so that a chunk's reads are in flight
+    // while the previous chunk's MFMAs issue (a plain loop pays the LDS round trip in front of every MFMA)
+    auto mfma_chain = [&](int n, auto fa, auto fb, f32x16 acc) {
+        for (int i0 = 0; i0 < n; i0 += 8) {
+            float av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {                             // (loads unconditional, at clamped indices: a load under a run-time
+                const int i = min(i0 + u, n - 1);                     //  condition becomes a branch with its own wait per element)
+                av[u] = fa(i) * (i0 + u < n ? 1.f : 0.f); bv[u] = fb(i);
+            }
+            __builtin_amdgcn_sched_barrier(0);                        // (at the register cap hipcc sinks each read to its MFMA otherwise)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return acc;
+    };
+    f32x16 accWd, accWc;                                             // LSA: d(Wd) tile of waves 2..5, d(Wc) tile of waves 5..6, summed over all steps
 #pragma unroll
     for (int e = 0; e < 16; ++e) { accWd[e] = 0.f; accWc[e] = 0.f; }
     float ain[6];                                                   // per thread: q_a | p_j (LSA: w_j), a_prev_j (LSA: [w; cum](t-1) with halos), dalign_j | two direct dctx sources
@@ -526,9 +545,6 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
             float* wnew = wpadL + (t & 1) * 2 * TwP;                     // [w_{t-1}; cum_{t-1}] of THIS step, halos included
             const float* wold = wpadL + ((t + 1) & 1) * 2 * TwP;         // ... of step t+1 (whose dloc is in dlocL)
             const int njt = (len + 31) / 32;
-            float wdf[16];                                               // Wd[lat*32 + r][2i + hk]: B operand of the pa product (L2-resident; requested here, used below)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { const int f = 2 * i + hk; wdf[i] = f < F ? AS.loc_dense[(long)(lat * 32 + r) * F + f] : 0.f; }
             // ------------------------------------------------------------------------------------------------------------
             // In front of the poll (none of it needs the context gradient of this step): halo rows of dloc(t+1) from the
             // other split, gradient carried to w_t / cum_t, d(Wc) of step t+1, location features and tanh tile of step t.
@@ -549,6 +565,9 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
             if (tid < len) wL[tid] = in[1];
             if (tid < 2 * WN) { const int c = tid / WN; wnew[c * TwP + (tid - c * WN)] = in[2]; }
             __syncthreads();
+            T2_BSTAMP(11);
+            // work units of this stage over the 8 waves: 0,1 location features of the two position tiles; 2,3,4 the six Q tiles
+            // (two each); 5,6 the two d(Wc) column tiles
             if (wave < njt) {
                 // loc[j][f] = sum_{c,k} Wc[f][c][k] wcat[c][j + k - pad]: Toeplitz product on the matrix cores (exact fp32 fma chains)
                 const float* xr = wnew + min(wave * 32 + r, len - 1);
@@ -556,76 +575,84 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                 f32x16 acc;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-                for (int kk = 0; kk < 2 * Kc; kk += 2) {
-                    const int ck = kk + hk, c = ck >= Kc ? 1 : 0, k = ck - c * Kc;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[c * TwP + k], wr[ck], acc, 0, 0, 0);
-                }
+                acc = mfma_chain(Kc, [&](int i) { const int ck = 2 * i + hk, c = ck >= Kc ? 1 : 0; return xr[c * TwP + ck - c * Kc]; },
+                                 [&](int i) { return wr[2 * i + hk]; }, acc);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int jl = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk;
                     if (jl < len && r < F) locL[jl * F1 + r] = acc[e];
                 }
                 if (hk == 0 && wave * 32 + r < len) locL[(wave * 32 + r) * F1 + F] = 0.f;      // pad column (K of the products below is even)
-            } else if (wave < 4) {
-                if (ep > 0 && wave >= 2 && wave - 2 < (2 * Kc + 31) / 32) {
-                    // d(Wc)[f][(c,k)] += sum_j dloc(t+1)[j][f] wcat(t+1)[c][j + k - pad]   (rows f, columns (c,k), K = own positions)
-                    const int n = min((wave - 2) * 32 + r, 2 * Kc - 1), c = n / Kc, k = n - c * Kc;
-                    const float* ar = dlocL + (pad + hk) * F1 + min(r, F);
-                    const float* br = wold + c * TwP + k + hk;
-                    const int le = (len + 1) & ~1;
-                    for (int kk = 0; kk < le; kk += 2) {
-                        const bool ok = kk + hk < len;
-                        accWc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? ar[kk * F1] : 0.f, ok ? br[kk] : 0.f, accWc, 0, 0, 0);
-                    }
-                }
-            } else if (ep > 0) {
-                // gradient on [w_t; cum_t] through the location conv of step t+1:
-                // dwcat[c][i] = sum_{f,k} Wc[f][c][k] dloc[i - k + pad][f]; work item (f group of 8, c, 4 positions), window sliding downwards
-                const int t0 = tid - 256, ni4 = (len + 3) / 4, Tp4 = ni4 * 4;
-                float* tmp = lredL;                                       // [8][2][Tp4]
-                if (t0 < 8 * 2 * ni4) {
-                    const int fq = t0 / (2 * ni4), c = (t0 / ni4) % 2, i0 = (t0 % ni4) * 4;
-                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-                    for (int f = fq; f < F; f += 8) {
-                        const float* w = convwL + (f * 2 + c) * Kc;
-                        const float* dl = dlocL + (i0 + 2 * pad) * F1 + f;    // row of position i0 - k + pad at k = 0
-                        float d3 = dl[3 * F1], d2 = dl[2 * F1], d1 = dl[F1];
-                        for (int k = 0; k < Kc; ++k) {
-                            const float d0 = dl[-k * F1], wk = w[k];
-                            s0 += wk * d0; s1 += wk * d1; s2 += wk * d2; s3 += wk * d3;
-                            d3 = d2; d2 = d1; d1 = d0;
+            }
+            if (ep > 0 && wave >= 2 && wave < 5) {
+                // gradient on [w_t; cum_t] through the location conv of step t+1, dwcat[c][i] = sum_{f,k} Wc[f][c][k] dloc[i - k + pad][f],
+                // in two steps: Q[p][(c,k)] = sum_f dloc[p][f] Wc[f][(c,k)] on the matrix cores (rows p = own positions and both
+                // halos: 3 x 2 tiles), then dwcat[c][i] = the anti-diagonal sum_k Q[i + 2 pad - k][(c,k)]
+                const int NP = len + 2 * pad, pt = wave - 2;
+                for (int nq = 0; nq < 2; ++nq) {
+                    if (pt * 32 < NP && nq * 32 < 2 * Kc) {
+                        const float* ar = dlocL + min(pt * 32 + r, NP - 1) * F1 + hk;
+                        const float* br = convwL + hk * 2 * Kc + min(nq * 32 + r, 2 * Kc - 1);
+                        f32x16 acc;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                        acc = mfma_chain(F / 2, [&](int i) { return ar[2 * i]; }, [&](int i) { return br[2 * i * 2 * Kc]; }, acc);
+                        const int n = nq * 32 + r;
+                        if (n < 2 * Kc) {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const int p = pt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk;
+                                if (p < NP) utL[p * 65 + n] = acc[e];
+                            }
                         }
                     }
-                    float* tp = tmp + (fq * 2 + c) * Tp4 + i0;
-                    tp[0] = s0; tp[1] = s1; tp[2] = s2; tp[3] = s3;
                 }
             }
+            if (ep > 0 && wave >= 5 && wave < 7 && (wave - 5) * 32 < 2 * Kc) {
+                // d(Wc)[f][(c,k)] += sum_j dloc(t+1)[j][f] wcat(t+1)[c][j + k - pad]   (rows f, columns (c,k), K = own positions)
+                const int n = min((wave - 5) * 32 + r, 2 * Kc - 1), c = n / Kc, k = n - c * Kc;
+                const float* ar = dlocL + (pad + hk) * F1 + min(r, F);
+                const float* br = wold + c * TwP + k + hk;
+                accWc = mfma_chain((len + 1) / 2, [&](int i) { return ar[min(2 * i, len - 1 - hk) * F1] * (2 * i + hk < len ? 1.f : 0.f); }, [&](int i) { return br[2 * i]; }, accWc);
+            }
             __syncthreads();
-            if (ep > 0 && tid < 2 * len) {
-                const int c = tid / len, i = tid - c * len, Tp4 = ((len + 3) / 4) * 4;
-                float sum = 0.f;
+            T2_BSTAMP(12);
+            // operands of the tanh tile further down (L2-resident rows of Wd and of the processed memory): requested here,
+            // in flight underneath the diagonal sums and the first MFMAs below (held across the whole stage above they spill)
+            float wdf[16], pv[16];
 #pragma unroll
-                for (int fq = 0; fq < 8; ++fq) sum += lredL[(fq * 2 + c) * Tp4 + i];
+            for (int i = 0; i < 4; ++i) {                                // K index (i, hk) of the pa product <-> feature f = 16 hk + i: 64 contiguous bytes per lane
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(AS.loc_dense + (long)(lat * 32 + r) * F + 16 * hk + 4 * i);
+                wdf[4 * i] = w4[0]; wdf[4 * i + 1] = w4[1]; wdf[4 * i + 2] = w4[2]; wdf[4 * i + 3] = w4[3];
+            }
+            {
+                const float* pmr = AS.pm + ((long)ab_ * Tin + jb) * A + lat * 32 + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) pv[e] = pmr[(long)min(min(ljt, njt - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk, len - 1) * A];
+            }
+            if (ep > 0 && tid < 2 * len) {
+                const int c = tid / len, i = tid - c * len;
+                const float* qp = utL + (i + 2 * pad) * 65 + c * Kc;
+                float sum = 0.f;
+                for (int k = 0; k < Kc; ++k) sum += qp[-k * 64];
                 if (c == 0) carryL[i] = sum; else ccL[i] += sum;
             }
+            __syncthreads();
             // pa = loc . Wd^T for this wave's [32 positions x 32 channels] tile, then u = tanh(q + pm + pa) into the tile
             if (ljt < njt) {
-                const float* lr = locL + min(ljt * 32 + r, len - 1) * F1 + hk;
+                const float* lr = locL + min(ljt * 32 + r, len - 1) * F1 + 16 * hk;
                 f32x16 acc;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                {
+                    float lv[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (2 * i < ((F + 1) & ~1)) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lr[2 * i], wdf[i], acc, 0, 0, 0);
+                    for (int i = 0; i < 16; ++i) lv[i] = lr[i];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lv[i], wdf[i], acc, 0, 0, 0);
+                }
                 const int a = lat * 32 + r;
                 const float qa = qL[a];
-                const float* pmr = AS.pm + ((long)ab_ * Tin + jb) * A + a;
-                float pv[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int jl = min(ljt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk, len - 1);
-                    pv[e] = pmr[(long)jl * A];
-                }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int jl = ljt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk;
@@ -633,6 +660,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                 }
             }
             // ------------------------------------------------------------------------------------------------------------
+            T2_BSTAMP(13);
             if (ep > 0) {
                 if (wave == 0 && !poll_counter(CNT(2 + as), ep * (unsigned)(NTC * AKP), d.err, 7u) && lane == 0) *abortw = 1;
                 __syncthreads();
@@ -781,11 +809,8 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
             } else if (wave >= 2 && wave < 6) {
                 const float* ar = utL + hk * UP + (wave - 2) * 32 + r;
                 const float* br = locL + hk * F1 + min(r, F);
-                const int le = (len + 1) & ~1;
-                for (int kk = 0; kk < le; kk += 2) {
-                    const bool ok = kk + hk < len;
-                    accWd = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? ar[kk * UP] : 0.f, ok ? br[kk * F1] : 0.f, accWd, 0, 0, 0);
-                }
+                accWd = mfma_chain((len + 1) / 2, [&](int i) { return ar[min(2 * i, len - 1 - hk) * UP] * (2 * i + hk < len ? 1.f : 0.f); },
+                                   [&](int i) { return br[min(2 * i, len - 1 - hk) * F1]; }, accWd);
             }
             __syncthreads();
             // hand-offs: dq partial of this split, the `pad` rows of dloc next to the boundary
@@ -957,7 +982,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
     // ---------------------------------------------------------------- A epilogue: the accumulators leave LDS
     if (hasA) {
         if constexpr (KIND == CHAIN_LSA) {
-            // location-layer weight gradients of this (split, item): the MFMA accumulators of waves 2..5 / 2..3
+            // location-layer weight gradients of this (split, item): the MFMA accumulators of waves 2..5 / 5..6
             if (wave >= 2 && wave < 6 && r < F) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -965,8 +990,8 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                     AS.ddense_acc[(((long)split * B + ab_) * A + a) * F + r] = accWd[e];
                 }
             }
-            const int n = (wave - 2) * 32 + r;
-            if (wave >= 2 && wave < 4 && n < 2 * Kc) {
+            const int n = (wave - 5) * 32 + r;
+            if (wave >= 5 && wave < 7 && n < 2 * Kc) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int f = (e & 3) + 8 * (e >> 2) + 4 * hk;
@@ -990,7 +1015,7 @@ bool chain_bwd_plan(ChainBwdDesc& d) {
     if (d.kind == CHAIN_LSTM) return true;
     if ((d.kind != CHAIN_SMA && d.kind != CHAIN_LSA) || d.E != 512 || d.A != 128 || d.NS < 1 || d.NS > 2) return false;
     const bool lsa = d.kind == CHAIN_LSA;
-    if (lsa && (d.F < 4 || d.F > 32 || d.F % 4 != 0 || d.Kc < 3 || d.Kc > 31 || d.Kc % 2 == 0)) return false;
+    if (lsa && (d.F != 32 || d.Kc < 3 || d.Kc > 31 || d.Kc % 2 == 0)) return false;     // (F = 32: the reference's attention_location_n_filters)
     const int pad = lsa ? (d.Kc - 1) / 2 : 0;
     int tc = 0;
     for (int s = 0; s < d.NS; ++s) {
