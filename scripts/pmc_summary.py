@@ -27,8 +27,11 @@ def load(d, counter):
                 kind = int(targs.group(1).split(",")[4]) if targs else -1
                 dec = targs and int(targs.group(1).split(",")[5]) > 0 if targs and len(targs.group(1).split(",")) > 5 else False
                 key = "chain_fwd_" + {0: "lstm", 1: "sma", 2: "lsa"}.get(kind, "x") + ("_decode" if dec else "")
-            elif short in ("chain_bwd_sma", "chain_bwd_lstm"):
+            elif short == "chain_bwd_lstm":
                 key = short
+            elif short == "chain_bwd_att":              # <MT, kind>: 1 = SMA, 2 = LSA
+                targs = re.search(r"chain_bwd_att_kernel<([^>]*)>", name)
+                key = "chain_bwd_" + {"1": "sma", "2": "lsa"}.get(targs.group(1).split(",")[1].strip() if targs else "", "x")
             out.setdefault(key, []).append(float(r["Counter_Value"]))
     return out
 
