@@ -243,8 +243,8 @@ __host__ __device__ inline BwdLds bwd_lds_of(int A, int E, int Tc, int MT, int k
     m.pm = take(lsa ? 0 : Tc * A); m.dpm = take(Tc * A); m.mem = take((Tc + 1) * E / 2);
     // LSA: carried gradient on the cumulative weights, conv weights, dloc of the last step with `pad` halo rows on both
     // sides (pitch F + 1, column F stays zero), [w_prev; cum_prev] of two steps (ping-pong) with the same halos
-    m.TwP = (Tc + 2 * pad + 3) & ~3;
-    m.cc = take(lsa ? Tc + 8 : 0); m.convw = take(lsa ? F * 2 * Kc : 0); m.dloc = take(lsa ? (Tc + 2 * pad) * (F + 1) : 0);
+    m.TwP = (Tc + 2 * pad + 8 + 3) & ~3;                    // (+8: the conv product's K is padded to a multiple of 16 with zero weights)
+    m.cc = take(lsa ? Tc + 8 : 0); m.convw = take(lsa ? F * ((2 * Kc + 15) & ~15) : 0); m.dloc = take(lsa ? (Tc + 2 * pad) * (F + 1) : 0);
     m.wpad = take(lsa ? 4 * m.TwP : 0);
     // scratch shared by the phases; LSA's A phase: tanh / dpre tile [Tc][A + 4], location features [Tc][F + 1], reduction rows
     // (the tile's room first holds Q = dloc . Wc^T, [Tc + 2 pad][65], of the carried-gradient step)
@@ -335,29 +335,43 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
     // ---------------------------------------------------------------- A setup: resident rows, zeroed accumulators
     // LSA (attention.py:26-85) geometry and buffers
     const int F = d.F, Kc = d.Kc, F1 = F + 1, pad = (Kc - 1) / 2, TwP = M.TwP, UP = A + 4, WN = len + 2 * pad;
+    const int CP = (2 * Kc + 15) & ~15;                              // pitch of the conv weights in LDS: [F][CP], columns >= 2 Kc zero
     float* wL = smem + M.ps;                                         // softmax weights of the step (own positions)
     float* ccL = smem + M.cc; float* convwL = smem + M.convw; float* dlocL = smem + M.dloc; float* wpadL = smem + M.wpad;
     float* utL = smem + M.scratch + M.ut; float* locL = smem + M.scratch + M.loc; float* lredL = smem + M.scratch + M.red;
-    (void)F1; (void)TwP; (void)UP; (void)WN; (void)wL; (void)ccL; (void)convwL; (void)dlocL; (void)wpadL; (void)utL; (void)locL; (void)lredL;
+    (void)F1; (void)TwP; (void)UP; (void)WN; (void)CP; (void)wL; (void)ccL; (void)convwL; (void)dlocL; (void)wpadL; (void)utL; (void)locL; (void)lredL;
     const int ljt = wave >> 2, lat = wave & 3;                       // LSA: this wave's (position tile, channel tile) of the [len x A] tile
+    // one bf16 MFMA operand (8 consecutive K values of this lane) gathered from fp32 LDS values
+    auto pack8 = [&](auto f) {
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (__bf16)f(i);
+        return o;
+    };
     // n chained fp32 MFMAs whose operands come from LDS: requested 8 pairs at a time, so that a chunk's reads are in flight
     // while the previous chunk's MFMAs issue (a plain loop pays the LDS round trip in front of every MFMA)
     auto mfma_chain = [&](int n, auto fa, auto fb, f32x16 acc) {
+        f32x16 acc2;                                                  // two interleaved chains: a dependent fp32 MFMA waits out the previous one
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
         for (int i0 = 0; i0 < n; i0 += 8) {
             float av[8], bv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {                             // (loads unconditional, at clamped indices: a load under a run-time
-                const int i = min(i0 + u, n - 1);                     //  condition becomes a branch with its own wait per element)
-                av[u] = fa(i) * (i0 + u < n ? 1.f : 0.f); bv[u] = fb(i);
-            }
+            for (int u = 0; u < 8; ++u) { av[u] = fa(i0 + u); bv[u] = fb(i0 + u); }   // (n % 8 == 0: no per-element condition — a load under a
+                                                                                       //  run-time condition becomes a branch or a wait per element)
             __builtin_amdgcn_sched_barrier(0);                        // (at the register cap hipcc sinks each read to its MFMA otherwise)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+            for (int u = 0; u < 8; u += 2) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u + 1], bv[u + 1], acc2, 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] += acc2[e];
         return acc;
     };
-    f32x16 accWd, accWc;                                             // LSA: d(Wd) tile of waves 2..5, d(Wc) tile of waves 5..6, summed over all steps
+    f32x16 accWd, accWc;                                             // LSA: d(Wd) tile of waves 2..5, d(Wc) tile of waves 2..3, summed over all steps
 #pragma unroll
     for (int e = 0; e < 16; ++e) { accWd[e] = 0.f; accWc[e] = 0.f; }
     float ain[6];                                                   // per thread: q_a | p_j (LSA: w_j), a_prev_j (LSA: [w; cum](t-1) with halos), dalign_j | two direct dctx sources
@@ -396,7 +410,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
         for (int j = tid; j < chunk + 8; j += NTH) carryL[j] = 0.f;
         if constexpr (KIND == CHAIN_LSA) {
             for (int j = tid; j < chunk + 8; j += NTH) ccL[j] = 0.f;
-            for (int i = tid; i < F * 2 * Kc; i += NTH) convwL[i] = AS.loc_conv[i];
+            for (int i = tid; i < F * CP; i += NTH) { const int f = i / CP, ck = i - f * CP; convwL[i] = ck < 2 * Kc ? AS.loc_conv[f * 2 * Kc + ck] : 0.f; }
             for (int i = tid; i < (d.lds_Tc + 2 * pad) * F1; i += NTH) dlocL[i] = 0.f;
             for (int i = tid; i < 4 * TwP; i += NTH) wpadL[i] = 0.f;
         }
@@ -571,11 +585,12 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
             if (wave < njt) {
                 // loc[j][f] = sum_{c,k} Wc[f][c][k] wcat[c][j + k - pad]: Toeplitz product on the matrix cores (exact fp32 fma chains)
                 const float* xr = wnew + min(wave * 32 + r, len - 1);
-                const float* wr = convwL + min(r, F - 1) * 2 * Kc;
+                const float* wr = convwL + min(r, F - 1) * CP;
                 f32x16 acc;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-                acc = mfma_chain(Kc, [&](int i) { const int ck = 2 * i + hk, c = ck >= Kc ? 1 : 0; return xr[c * TwP + ck - c * Kc]; },
+                // K = CP (2 Kc padded with zero weights: the matching [w; cum] reads stay inside the padded row)
+                acc = mfma_chain(CP / 2, [&](int i) { const int ck = 2 * i + hk, c = ck >= Kc ? 1 : 0; return xr[c * TwP + ck - c * Kc]; },
                                  [&](int i) { return wr[2 * i + hk]; }, acc);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -584,41 +599,49 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                 }
                 if (hk == 0 && wave * 32 + r < len) locL[(wave * 32 + r) * F1 + F] = 0.f;      // pad column (K of the products below is even)
             }
-            if (ep > 0 && wave >= 2 && wave < 5) {
+            if (ep > 0 && wave >= 2) {
                 // gradient on [w_t; cum_t] through the location conv of step t+1, dwcat[c][i] = sum_{f,k} Wc[f][c][k] dloc[i - k + pad][f],
                 // in two steps: Q[p][(c,k)] = sum_f dloc[p][f] Wc[f][(c,k)] on the matrix cores (rows p = own positions and both
-                // halos: 3 x 2 tiles), then dwcat[c][i] = the anti-diagonal sum_k Q[i + 2 pad - k][(c,k)]
-                const int NP = len + 2 * pad, pt = wave - 2;
-                for (int nq = 0; nq < 2; ++nq) {
-                    if (pt * 32 < NP && nq * 32 < 2 * Kc) {
-                        const float* ar = dlocL + min(pt * 32 + r, NP - 1) * F1 + hk;
-                        const float* br = convwL + hk * 2 * Kc + min(nq * 32 + r, 2 * Kc - 1);
-                        f32x16 acc;
+                // halos: 3 x 2 tiles, one per wave 2..7), then dwcat[c][i] = the anti-diagonal sum_k Q[i + 2 pad - k][(c,k)].
+                // bf16 operands, as every gradient product of this mode (the fp32 pipe is what bounds this phase: 64 cycles per
+                // K = 2 against 32 per K = 16).
+                const int NP = len + 2 * pad, pt = (wave - 2) >> 1, nq = (wave - 2) & 1;
+                if (pt * 32 < NP && nq * 32 < 2 * Kc) {
+                    const float* ar = dlocL + min(pt * 32 + r, NP - 1) * F1 + 8 * hk;
+                    const float* br = convwL + 8 * hk * CP + min(nq * 32 + r, 2 * Kc - 1);
+                    f32x16 acc;
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-                        acc = mfma_chain(F / 2, [&](int i) { return ar[2 * i]; }, [&](int i) { return br[2 * i * 2 * Kc]; }, acc);
-                        const int n = nq * 32 + r;
-                        if (n < 2 * Kc) {
+                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-                            for (int e = 0; e < 16; ++e) {
-                                const int p = pt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk;
-                                if (p < NP) utL[p * 65 + n] = acc[e];
-                            }
+                    for (int ks = 0; ks < 2; ++ks)                       // (F = 32)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8([&](int i) { return ar[16 * ks + i]; }),
+                                                                        pack8([&](int i) { return br[(16 * ks + i) * CP]; }), acc, 0, 0, 0);
+                    const int n = nq * 32 + r;
+                    if (n < 2 * Kc) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int p = pt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk;
+                            if (p < NP) utL[p * 65 + n] = acc[e];
                         }
                     }
                 }
-            }
-            if (ep > 0 && wave >= 5 && wave < 7 && (wave - 5) * 32 < 2 * Kc) {
-                // d(Wc)[f][(c,k)] += sum_j dloc(t+1)[j][f] wcat(t+1)[c][j + k - pad]   (rows f, columns (c,k), K = own positions)
-                const int n = min((wave - 5) * 32 + r, 2 * Kc - 1), c = n / Kc, k = n - c * Kc;
-                const float* ar = dlocL + (pad + hk) * F1 + min(r, F);
-                const float* br = wold + c * TwP + k + hk;
-                accWc = mfma_chain((len + 1) / 2, [&](int i) { return ar[min(2 * i, len - 1 - hk) * F1] * (2 * i + hk < len ? 1.f : 0.f); }, [&](int i) { return br[2 * i]; }, accWc);
+                if (wave < 4 && (wave - 2) * 32 < 2 * Kc) {
+                    // d(Wc)[f][(c,k)] += sum_j dloc(t+1)[j][f] wcat(t+1)[c][j + k - pad]   (rows f, columns (c,k), K = own positions)
+                    const int n = min((wave - 2) * 32 + r, 2 * Kc - 1), c = n / Kc, k = n - c * Kc;
+                    const float* ar = dlocL + pad * F1 + min(r, F);
+                    const float* br = wold + c * TwP + k;
+                    for (int ks = 0; ks * 16 < len; ++ks) {              // (uniform trip count: every lane takes part in an MFMA)
+                        const int j0 = ks * 16 + 8 * hk;
+                        accWc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            pack8([&](int i) { const float x = ar[min(j0 + i, len - 1) * F1]; return j0 + i < len ? x : 0.f; }),
+                            pack8([&](int i) { return br[min(j0 + i, len - 1)]; }), accWc, 0, 0, 0);
+                    }
+                }
             }
             __syncthreads();
             T2_BSTAMP(12);
             // operands of the tanh tile further down (L2-resident rows of Wd and of the processed memory): requested here,
-            // in flight underneath the diagonal sums and the first MFMAs below (held across the whole stage above they spill)
+            // in flight underneath the diagonal sums (requested in front of the products above they cost more than they hide: measured)
             float wdf[16], pv[16];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {                                // K index (i, hk) of the pa product <-> feature f = 16 hk + i: 64 contiguous bytes per lane
@@ -667,11 +690,6 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                 if (*abortw) return;
             } else __syncthreads();
             T2_BSTAMP(0);
-            bf16x8 wdt[8];                                               // Wd^T fragments (column f = r, channels 16i + 8hk ..) of the dloc product: waves 0..1
-            if (wave < njt) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) wdt[i] = *reinterpret_cast<const bf16x8*>(AS.wdt16 + (long)min(r, F - 1) * A + 16 * i + 8 * hk);
-            }
             if (tid < E) {
                 float v = in[4] + in[5];
                 if (ep > 0) {
@@ -787,19 +805,23 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                 dvaL[tid] += sv;
             }
             // dloc[j][f] = sum_a dpre[j][a] Wd[a][f] (waves 0..1, bf16 operands as every large product of this mode) and
-            // d(Wd)[a][f] += sum_j dpre[j][a] loc[j][f] (waves 2..5, exact fp32), both straight off the tile
+            // d(Wd)[a][f] += sum_j dpre[j][a] loc[j][f] (waves 2..5), both straight off the tile
             if (wave < njt) {
+                // Wd^T fragments (column f = r, channels 16i + 8hk ..): L2-resident, requested here (held across the tile pass they spill)
+                bf16x8 wdt[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wdt[i] = *reinterpret_cast<const bf16x8*>(AS.wdt16 + (long)min(r, F - 1) * A + 16 * i + 8 * hk);
                 f32x16 acc;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = 0.f;
                 const float* ur = utL + min(wave * 32 + r, len - 1) * UP + 8 * hk;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < 8; ++i) {                            // (A = 128)
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(ur + 16 * i), hi = *reinterpret_cast<const f32x4*>(ur + 16 * i + 4);
                     bf16x8 af;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { af[c] = (__bf16)lo[c]; af[4 + c] = (__bf16)hi[c]; }
-                    if (16 * i < A) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wdt[i], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wdt[i], acc, 0, 0, 0);
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -807,10 +829,14 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                     if (jl < len && r < F) dlocL[(pad + jl) * F1 + r] = acc[e];
                 }
             } else if (wave >= 2 && wave < 6) {
-                const float* ar = utL + hk * UP + (wave - 2) * 32 + r;
-                const float* br = locL + hk * F1 + min(r, F);
-                accWd = mfma_chain((len + 1) / 2, [&](int i) { return ar[min(2 * i, len - 1 - hk) * UP] * (2 * i + hk < len ? 1.f : 0.f); },
-                                   [&](int i) { return br[min(2 * i, len - 1 - hk) * F1]; }, accWd);
+                const float* ar = utL + (wave - 2) * 32 + r;
+                const float* br = locL + min(r, F);
+                for (int ks = 0; ks * 16 < len; ++ks) {
+                    const int j0 = ks * 16 + 8 * hk;
+                    accWd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        pack8([&](int i) { const float x = ar[min(j0 + i, len - 1) * UP]; return j0 + i < len ? x : 0.f; }),
+                        pack8([&](int i) { return br[min(j0 + i, len - 1) * F1]; }), accWd, 0, 0, 0);
+                }
             }
             __syncthreads();
             // hand-offs: dq partial of this split, the `pad` rows of dloc next to the boundary
@@ -982,7 +1008,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
     // ---------------------------------------------------------------- A epilogue: the accumulators leave LDS
     if (hasA) {
         if constexpr (KIND == CHAIN_LSA) {
-            // location-layer weight gradients of this (split, item): the MFMA accumulators of waves 2..5 / 5..6
+            // location-layer weight gradients of this (split, item): the MFMA accumulators of waves 2..5 / 2..3
             if (wave >= 2 && wave < 6 && r < F) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -990,8 +1016,8 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                     AS.ddense_acc[(((long)split * B + ab_) * A + a) * F + r] = accWd[e];
                 }
             }
-            const int n = (wave - 5) * 32 + r;
-            if (wave >= 5 && wave < 7 && n < 2 * Kc) {
+            const int n = (wave - 2) * 32 + r;
+            if (wave >= 2 && wave < 4 && n < 2 * Kc) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int f = (e & 3) + 8 * (e >> 2) + 4 * hk;
