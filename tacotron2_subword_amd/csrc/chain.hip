@@ -84,13 +84,13 @@ __host__ __device__ inline Lds lds_of(const ChainDesc& d, int UT, int RT, int Ti
         m.pm = take(Jp * (d.kind == CHAIN_LSA ? d.A + 1 : d.A)); m.mem = take(Jm * EC / 2);    // (LSA reads pm position-major: odd pitch)
     } else { m.v = m.ap = m.cum = m.q = m.e = m.an = m.cs = m.pm = m.mem = o; }
     m.convw = m.dense = o;
-    if (d.kind == CHAIN_LSA) { m.convw = take(d.F * 2 * d.Kc); m.dense = take(d.A * (d.F + 1)); }   // location layer weights, resident
+    if (d.kind == CHAIN_LSA) { m.convw = take(d.F * ((2 * d.Kc + 15) & ~15)); m.dense = take(d.A * (d.F + 1)); }   // location layer weights, resident (conv taps zero-padded to a multiple of 16)
     const int lpart = NWV * 32 * PPR, lhs = RT * 32 * (UT * 8 + 4), lq = d.kind == CHAIN_LSTM ? 0 : RT * 32 * (d.A + 4);
     const int lphase = (lpart > lq ? lpart : lq) + lhs;
     int aphase = d.kind == CHAIN_LSTM ? 0 : 16 * d.A + NWV * EC;
     m.loc = m.wpad = m.pa = 0;
     if (d.kind == CHAIN_LSA) {                               // per-step location features behind the reduction buffers
-        const int TwP = (Tin + d.Kc - 1 + 4 + 3) & ~3;
+        const int TwP = (Tin + d.Kc - 1 + 8 + 3) & ~3;
         m.loc = aphase; aphase += (Tin * (d.F + 1) + 3) & ~3;
         m.wpad = aphase; aphase += 2 * TwP;
         m.pa = aphase; aphase += (d.A / 32) * ((Tin + 3) & ~3);   // energy partials of the channel tiles [A/32][Tp]
@@ -209,8 +209,8 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             *reinterpret_cast<bf16x4*>(memL + j * EC + c4) = o;
         }
         if (KIND == CHAIN_LSA) {
-            const int F = d.F, Kc = d.Kc, F1 = F + 1;
-            for (int i = tid; i < F * 2 * Kc; i += NTH) convwL[i] = AS.loc_conv[i];
+            const int F = d.F, Kc = d.Kc, F1 = F + 1, CPW = (2 * Kc + 15) & ~15;
+            for (int i = tid; i < F * CPW; i += NTH) { const int f = i / CPW, ck = i - f * CPW; convwL[i] = ck < 2 * Kc ? AS.loc_conv[f * 2 * Kc + ck] : 0.f; }
             for (int i = tid; i < A * F1; i += NTH) denseL[i] = (i % F1) < F ? AS.loc_dense[(i / F1) * F + (i % F1)] : 0.f;
         }
         alen = AS.lengths ? AS.lengths[ab_] : Tin;
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 // on the matrix cores (exact fp32 fma chains).  It needs nothing of step t, so it runs HERE, in front of the poll:
                 // the workgroup would otherwise sit out the L phase's publish latency.  (The dense layer follows below, fused
                 // with the energies.)
-                const int F = d.F, Kc = d.Kc, F1 = F + 1, pad = (Kc - 1) / 2, Tw = Tin + Kc - 1, TwP = (Tw + 4 + 3) & ~3;
+                const int F = d.F, Kc = d.Kc, F1 = F + 1, pad = (Kc - 1) / 2, Tw = Tin + Kc - 1, TwP = (Tw + 8 + 3) & ~3, CPW = (2 * Kc + 15) & ~15;
                 for (int i = tid; i < 2 * TwP; i += NTH) {
                     const int c = i / TwP, j = i % TwP - pad;
                     wpadL[i] = (j >= 0 && j < Tin) ? (c == 0 ? apL[j] : cumL[j]) : 0.f;
@@ -532,13 +532,23 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 for (int tile = wave; tile < njt * nft; tile += NWV) {
                     const int jt = tile / nft, ft = tile % nft;
                     const float* xr = wpadL + min(jt * 32 + r_, Tin - 1);
-                    const float* wr = convwL + min(ft * 32 + r_, F - 1) * 2 * Kc;
+                    const float* wr = convwL + min(ft * 32 + r_, F - 1) * CPW;
                     f32x16 acc;
 #pragma unroll
                     for (int e2 = 0; e2 < 16; ++e2) acc[e2] = 0.f;
-                    for (int kk = 0; kk < 2 * Kc; kk += 2) {
-                        const int ck = kk + h_, c = ck >= Kc ? 1 : 0, k = ck - c * Kc;
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[c * TwP + k], wr[ck], acc, 0, 0, 0);
+                    // K = CPW (2 Kc zero-padded to a multiple of 16): operand pairs requested 8 at a time — a plain loop pays the
+                    // LDS round trip in front of every MFMA, and a tail mask costs a wait per element
+                    for (int k0 = 0; k0 < CPW; k0 += 16) {
+                        float av[8], bv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int ck = k0 + 2 * u + h_, c = ck >= Kc ? 1 : 0;
+                            av[u] = xr[c * TwP + ck - c * Kc]; bv[u] = wr[ck];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     const int f = ft * 32 + r_;
                     if (f < F) {
@@ -611,7 +621,15 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                     f32x16 acc;
 #pragma unroll
                     for (int e2 = 0; e2 < 16; ++e2) acc[e2] = 0.f;
-                    for (int kk = 0; kk < Ke; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dr[kk], lr[kk], acc, 0, 0, 0);
+                    for (int k0 = 0; k0 < Ke; k0 += 16) {                // (Ke = 32 at F = 32; operand pairs 8 at a time, as the conv above)
+                        float av[8], bv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { av[u] = dr[k0 + 2 * u]; bv[u] = lr[k0 + 2 * u]; }      // (F % 16 == 0: chain_plan)
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     const float* pr = pmL + j * (A + 1) + at * 32 + 4 * h_;
                     const float* qr = qL + at * 32 + 4 * h_;
                     const float* vr = vL + at * 32 + 4 * h_;
@@ -1023,7 +1041,7 @@ int chain_device_cus() {
 bool chain_plan(ChainDesc& d) {
     if (d.H != 1024 || d.B < 1 || d.B > 128) return false;
     if (d.kind != CHAIN_LSTM && (d.E != 512 || d.A != 128 || d.NS < 1 || d.NS > 2)) return false;
-    if (d.kind == CHAIN_LSA && (d.F + 1 > 64 || d.A % 32 != 0)) return false;
+    if (d.kind == CHAIN_LSA && (d.F + 1 > 64 || d.F % 16 != 0 || d.A % 32 != 0)) return false;
     const int MT = (d.B + 31) / 32;
     if (d.dec && (MT != 1 || d.NS != 2 || d.kind == CHAIN_LSTM || d.P != 256 || d.Hd != 1024 || d.M + 1 > 96 || d.M % 8 != 0)) return false;
     if (d.kind == CHAIN_LSTM) { d.UT = 1; d.RT = MT <= 2 ? MT : 2; d.CS = 1; d.NS = 1; }
