@@ -198,3 +198,44 @@ def test_config2_training_step_b64_bf16(env):
     errs.update({k: rel(G[k], P64[k].grad) for k in keys})
     print("decoder backward at T=400 vs fp64 oracle autograd (relative L2):", errs)
     assert max(errs.values()) < 2e-3, errs
+
+
+def test_lsa_training_step_b64_bf16(env):
+    """The same whole-step comparison for LocationSensitiveAttention (the other attention SURVEY section 8 names) at B=64 with
+    the BASELINE memory lengths and 160 frames: bf16 mode = persistent forward chain + the persistent LSA backward (two
+    position splits per item, halo rows and softmax-dot hand-off) against the fp32 mode's per-step launches."""
+    L, ops = env
+    from tacotron2_subword_amd.hparams import create_hparams
+    from tacotron2_subword_amd.loss_function import Tacotron2Loss
+    from tacotron2_subword_amd.model import BERT_Tacotron2
+    from tacotron2_subword_amd import train as T
+    hp = create_hparams()
+    hp.attention = "LocationSensitiveAttention"
+    B, Tin, Tsub, Tn = 64, 100, 60, 160
+    res = {}
+    for mode in ("f32", "bf16"):
+        L.set_precision(mode)
+        try:
+            torch.manual_seed(1234)
+            model = BERT_Tacotron2(hp).cuda().train()
+            x, y = model.parse_batch(T.synthetic_batch(hp, B, Tin, Tsub, Tn, seed=31))
+            L.prof_enable(8 * Tn + 64)
+            out = model(x)
+            loss = Tacotron2Loss()(out, y, x)[0]
+            loss.backward()
+            torch.cuda.synchronize()
+            prof = L.prof_collect()
+            assert prof["chain_a_bwd"][1] == (1 if mode == "bf16" else 0), prof      # the persistent LSA backward really ran
+            assert all(bool(torch.isfinite(o).all()) for o in out)
+            grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+            assert all(bool(torch.isfinite(g).all()) for g in grads.values())
+            res[mode] = (float(loss.detach()), grads)
+        finally:
+            L.set_precision("f32")
+    l32, g32 = res["f32"]
+    l16, g16 = res["bf16"]
+    print("LSA B=64 loss fp32 / bf16:", l32, l16)
+    assert abs(l16 - l32) < 0.05 * abs(l32)
+    worst = {k: float((g16[k] - g32[k]).norm()) / (float(g32[k].norm()) + 1e-12) for k in g32 if not k.endswith(".0.conv.bias")}
+    print("worst relative gradient deviations bf16 vs fp32 (LSA):", dict(sorted(worst.items(), key=lambda kv: -kv[1])[:5]))
+    assert set(g16) == set(g32) and max(worst.values()) < 0.3, worst
