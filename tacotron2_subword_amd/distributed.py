@@ -150,6 +150,24 @@ def apply_gradient_allreduce(module):
     for p in arena.params:
         p.register_post_accumulate_grad_hook(make_hook(p))
 
+    # The decoder's persistent kernels need every CU of the device: a reduction launched by an earlier backward node (the
+    # postnet's bucket) would otherwise hold some of them while the grid waits to become resident.  Work.wait() orders the
+    # launch stream behind the collective without blocking the host; finish() waits on the same handles again (harmless).
+    import weakref
+    from . import ops as _ops
+    mref = weakref.ref(module)
+
+    def before_persistent():
+        m = mref()
+        if m is None:                                # the wrapped module is gone: retire this entry
+            _ops.PRE_PERSISTENT.remove(before_persistent)
+            return
+        if m.needs_reduction:
+            for h in m._t2_arena.handles:
+                h.wait()
+
+    _ops.PRE_PERSISTENT.append(before_persistent)
+
     arena.first_done = False
 
     def pre_forward(mod, inputs):                    # distributed.py:175-178

@@ -127,6 +127,9 @@ class _DecoderFn(torch.autograd.Function):
         pre = cfg.get("pre")
         if pre is not None:                     # Decoder.prologue ran the memory-independent part on its own stream
             torch.cuda.current_stream().wait_event(pre["event"])
+        ops.check_chain_status()                # the previous iteration's persistent kernels ran to completion (no sync: long done)
+        for f in list(ops.PRE_PERSISTENT):
+            f()
         dp = ops.decoder_forward(W, dims, memory, memory_sub, mem_lengths, sub_lengths, mels,
                                  training=cfg["training"], prenet_dropout=cfg["prenet_dropout"], seed=cfg["seed"],
                                  dp=None if pre is None else pre["dp"])
@@ -160,6 +163,8 @@ class _DecoderFn(torch.autograd.Function):
         # an accumulation into an existing .grad would read it on this stream too early)
         dec = cfg["decoder"]
         keep = [] if (getattr(dec, "defer_weight_grads", False) and all(p.grad is None for p in dec.parameters())) else None
+        for f in list(ops.PRE_PERSISTENT):      # (e.g. gradient reductions launched by earlier backward nodes: see ops.PRE_PERSISTENT)
+            f()
         G, dm, dms = ops.decoder_backward(ctx.W, ctx.P, cfg["decoder"].dims, dp, memory, memory_sub, c(d_mel, mel_shape),
                                           c(d_gate, gate_shape), training=cfg["training"], prenet_dropout=cfg["prenet_dropout"],
                                           seed=cfg["seed"], d_align=cz(d_align), d_align_sub=cz(d_align_sub), defer=keep)
@@ -169,6 +174,7 @@ class _DecoderFn(torch.autograd.Function):
                 keep.clear()
             torch.autograd.Variable._execution_engine.queue_callback(_join)
         grads = tuple(G.get("decoder." + k) for k in cfg["keys"])
+        ops.queue_chain_status_check(dp)
         ctx.dp = None
         return (dm, dms, None, None, None, None) + grads
 

@@ -42,6 +42,42 @@ def rng_normal(seed: int, site: int, n: int, device="cuda") -> torch.Tensor:
     return out
 
 
+# Callables run (on the launching thread, with the launch stream current) right before a teacher-forced pass that may launch
+# persistent chain kernels.  A persistent grid needs every CU: a collective still running on another stream would keep
+# part of the grid from becoming resident until it ends, so distributed.apply_gradient_allreduce registers a callable here
+# that makes the launch stream wait for the reductions in flight (a stream-level wait, the host does not block).
+PRE_PERSISTENT = []
+
+# Status words of the persistent kernels of the last backward pass, copied to the host without a synchronisation and
+# checked when the next pass starts: an aborted chain (a hand-off that timed out) must not pass silently.
+_pending_status = None
+
+
+def queue_chain_status_check(dp) -> None:
+    global _pending_status
+    if not dp.ws.is_cuda:
+        return
+    host = torch.empty(4, dtype=torch.int32).pin_memory()
+    host.copy_(dp.ws[dp.layout.chain:dp.layout.chain + 4].view(torch.int32), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dp.ws.device))
+    _pending_status = (host, ev)
+
+
+def check_chain_status() -> None:
+    """Raises if the previous pass's persistent kernels did not run to completion (status words of t2_decoder_layout.chain)."""
+    global _pending_status
+    if _pending_status is None:
+        return
+    host, ev = _pending_status
+    _pending_status = None
+    ev.synchronize()
+    st = tuple(int(v) for v in host)
+    if any(st):
+        raise RuntimeError(f"t2amd: a persistent chain kernel of the previous pass aborted (status words {st}: a hand-off between "
+                           "workgroups timed out — is another process or another persistent kernel using this GPU?); its results are invalid")
+
+
 class DecoderPass:
     """Outputs + saved-activation workspace of one teacher-forced decoder pass."""
 

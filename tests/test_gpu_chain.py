@@ -168,3 +168,17 @@ def test_backward_consumes_chain_activations(env, att):
         worst[k] = float((res[True][k] - v).norm()) / n
     print("relative gradient deviation chain vs launches:", dict(sorted(worst.items(), key=lambda kv: -kv[1])[:6]))
     assert max(worst.values()) < 0.05, worst
+
+
+def test_aborted_chain_is_reported_at_the_next_pass(env):
+    """The training path checks the persistent kernels' status words of the previous backward when the next pass starts
+    (asynchronous copy, no extra synchronisation): a chain that timed out must raise, not train on garbage."""
+    L, ops = env
+    out, st, (W, P, dims, dp, mem, mems) = _run(env, SMA, 8, 21, 12, 6, chain=True, training=True)
+    ops.queue_chain_status_check(dp)
+    ops.check_chain_status()                                         # clean pass: nothing raised
+    ops.check_chain_status()                                         # nothing pending: a no-op
+    dp.ws[dp.layout.chain + 3:dp.layout.chain + 4].view(torch.int32).fill_(7)      # as if the backward attention chain had aborted
+    ops.queue_chain_status_check(dp)
+    with pytest.raises(RuntimeError, match="persistent chain"):
+        ops.check_chain_status()
