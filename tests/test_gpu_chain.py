@@ -126,8 +126,12 @@ def test_backward_chain_matches_per_step_backward(env, att):
                 g = torch.Generator(device="cuda").manual_seed(3)
                 dmel = torch.randn(B, T, 80, device="cuda", generator=g)
                 dgate = torch.randn(B, T, device="cuda", generator=g)
+                # external gradients on the alignments too (the alignment-guide losses of loss_function.py produce them)
+                dal = 0.1 * torch.randn(B, T, Tin, device="cuda", generator=g)
+                dals = 0.1 * torch.randn(B, T, Tsub, device="cuda", generator=g)
                 L.prof_enable(8 * T + 64)
-                G, dm, dms = ops.decoder_backward(W, P, dims, dp, mem, mems, dmel, dgate, training=True, prenet_dropout=True, seed=11)
+                G, dm, dms = ops.decoder_backward(W, P, dims, dp, mem, mems, dmel, dgate, training=True, prenet_dropout=True, seed=11,
+                                                  d_align=dal, d_align_sub=dals)
                 torch.cuda.synchronize()
                 prof = L.prof_collect()
                 assert not any(dp.chain_status()), dp.chain_status()
