@@ -328,16 +328,24 @@ def main():
             T.train_step(model, criterion, optimizer, xf, yf, hp, it)
         torch.cuda.synchronize()
         tf0 = time.perf_counter()
+        marks = []
         for i in range(a.steps):
             xf, yf = model.parse_batch(D.batch_to_device(hb[i % 4]))
+            marks.append(time.perf_counter())                          # parse_batch's .item() has drained the previous step
             T.train_step(model, criterion, optimizer, xf, yf, hp, it)
         torch.cuda.synchronize()
         dtf = time.perf_counter() - tf0
+        marks.append(time.perf_counter())
+        step_ms = [round(1e3 * (marks[i + 1] - marks[i]), 2) for i in range(len(marks) - 1)]
+        med = sorted(step_ms)[len(step_ms) // 2]
         fresh = dict(ms_per_step=round(1e3 * dtf / a.steps, 2), value=round(B * Tn * a.steps / dtf, 1), unit="mel-frames/s",
+                     step_ms=step_ms, ms_per_step_median=med, value_at_median=round(B * Tn / (1e-3 * med), 1),
                      host_batches=4, bytes_per_batch=int(sum(v.numel() * v.element_size() if torch.is_tensor(v) else v.nbytes
                                                              for k, v in hb[0].items() if k != "align")),
                      note="every step: data_utils.batch_to_device (pinned staging + non-blocking H2D of the next ragged host batch) "
-                          "+ parse_batch (.item() syncs) + the training iteration; PCIe-inclusive, never `value`")
+                          "+ parse_batch (.item() syncs) + the training iteration; PCIe-inclusive, never `value`.  The loop "
+                          "drains the queue every step, so a host-side pause (a busy neighbour on the shared host, the Python "
+                          "collector) lands in a step: step_ms lists the steps, ms_per_step is their mean, the median is beside it")
 
     # one extra, untimed, profiled step: HIP events around every per-step decoder kernel launch
     roof, kernels = None, None

@@ -18,6 +18,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 echo "bench profile done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_infer -o ip -- python3 $R/bench.py --workload infer --steps 2 --warmup 1 > $O/prof_infer.log 2>&1 < /dev/null
 echo "infer profile done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lsa -o lp -- python3 $R/bench.py --attention lsa --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/prof_lsa.log 2>&1 < /dev/null
+echo "lsa profile done"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pf -- python3 $R/scripts/time_decoder.py --T 400 --iters 1 --prof 0 > $O/pmc_fetch.log 2>&1 < /dev/null
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o pw -- python3 $R/scripts/time_decoder.py --T 400 --iters 1 --prof 0 > $O/pmc_write.log 2>&1 < /dev/null
 echo "pmc traffic done"

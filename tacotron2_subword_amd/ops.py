@@ -48,34 +48,41 @@ def rng_normal(seed: int, site: int, n: int, device="cuda") -> torch.Tensor:
 # that makes the launch stream wait for the reductions in flight (a stream-level wait, the host does not block).
 PRE_PERSISTENT = []
 
-# Status words of the persistent kernels of the last backward pass, copied to the host without a synchronisation and
-# checked when the next pass starts: an aborted chain (a hand-off that timed out) must not pass silently.
-_pending_status = None
+# Status words of the persistent kernels of a backward pass, copied to the host without a synchronisation and checked at
+# a later pass once the copy has landed (never blocking the host): an aborted chain (a hand-off that timed out) must not
+# pass silently.  A small pool of page-locked slots is reused (allocating page-locked memory per step is slow).
+_status_pending = []          # [(host int32[4], event)] in launch order
+_status_free = []
 
 
 def queue_chain_status_check(dp) -> None:
-    global _pending_status
     if not dp.ws.is_cuda:
         return
-    host = torch.empty(4, dtype=torch.int32).pin_memory()
+    if len(_status_pending) >= 8:                   # nobody has looked for a while: settle the oldest (long finished)
+        _status_pending[0][1].synchronize()
+        check_chain_status()
+    host = _status_free.pop() if _status_free else torch.empty(4, dtype=torch.int32).pin_memory()
     host.copy_(dp.ws[dp.layout.chain:dp.layout.chain + 4].view(torch.int32), non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dp.ws.device))
-    _pending_status = (host, ev)
+    _status_pending.append((host, ev))
 
 
-def check_chain_status() -> None:
-    """Raises if the previous pass's persistent kernels did not run to completion (status words of t2_decoder_layout.chain)."""
-    global _pending_status
-    if _pending_status is None:
-        return
-    host, ev = _pending_status
-    _pending_status = None
-    ev.synchronize()
-    st = tuple(int(v) for v in host)
-    if any(st):
-        raise RuntimeError(f"t2amd: a persistent chain kernel of the previous pass aborted (status words {st}: a hand-off between "
-                           "workgroups timed out — is another process or another persistent kernel using this GPU?); its results are invalid")
+def check_chain_status(block: bool = False) -> None:
+    """Raises if a previous pass's persistent kernels did not run to completion (status words of t2_decoder_layout.chain).
+    Looks only at passes whose status copy has arrived unless `block`."""
+    while _status_pending:
+        host, ev = _status_pending[0]
+        if block:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        _status_pending.pop(0)
+        st = tuple(int(v) for v in host)
+        _status_free.append(host)
+        if any(st):
+            raise RuntimeError(f"t2amd: a persistent chain kernel of an earlier pass aborted (status words {st}: a hand-off between "
+                               "workgroups timed out — is another process or another persistent kernel using this GPU?); its results are invalid")
 
 
 class DecoderPass:
