@@ -55,8 +55,16 @@ _status_pending = []          # [(host int32[4], event)] in launch order
 _status_free = []
 
 
-def queue_chain_status_check(dp) -> None:
+_status_calls = 0
+STATUS_CHECK_EVERY = 16       # passes between two status copies (a timed-out hand-off costs seconds: it is noticed either way)
+
+
+def queue_chain_status_check(dp, force: bool = False) -> None:
+    global _status_calls
     if not dp.ws.is_cuda:
+        return
+    _status_calls += 1
+    if not force and (_status_calls - 1) % STATUS_CHECK_EVERY != 0:
         return
     if len(_status_pending) >= 8:                   # nobody has looked for a while: settle the oldest (long finished)
         _status_pending[0][1].synchronize()

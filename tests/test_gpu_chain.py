@@ -180,11 +180,11 @@ def test_aborted_chain_is_reported_at_the_next_pass(env):
     L, ops = env
     out, st, (W, P, dims, dp, mem, mems) = _run(env, SMA, 8, 21, 12, 6, chain=True, training=True)
     ops.check_chain_status(block=True)                               # (whatever earlier tests left pending)
-    ops.queue_chain_status_check(dp)
+    ops.queue_chain_status_check(dp, force=True)
     ops.check_chain_status(block=True)                               # clean pass: nothing raised
     ops.check_chain_status()                                         # nothing pending: a no-op
     dp.ws[dp.layout.chain + 3:dp.layout.chain + 4].view(torch.int32).fill_(7)      # as if the backward attention chain had aborted
-    ops.queue_chain_status_check(dp)
+    ops.queue_chain_status_check(dp, force=True)
     torch.cuda.synchronize()
     with pytest.raises(RuntimeError, match="persistent chain"):
         ops.check_chain_status()                                     # the non-blocking form finds the copy landed
