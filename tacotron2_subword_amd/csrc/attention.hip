@@ -1782,7 +1782,7 @@ int attention_step_fwd(const AttnStepDesc& din, hipStream_t s) {
                              (size_t)d.A * kDcaUT + 2 * d.A + 12) * sizeof(float);
         T2_REQUIRE(smem <= 160 * 1024, "attention_step (DCA): T_in too long for LDS (%zu bytes)", smem);
         if (smem > 64 * 1024)
-            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_dca_step_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            T2_TRY_RC(t2_allow_dynamic_lds(reinterpret_cast<const void*>(attention_dca_step_fwd_kernel), smem));
         hipLaunchKernelGGL(attention_dca_step_fwd_kernel, dim3(d.B, d.nstreams), dim3(NT), smem, s, d);
         T2_LAUNCH_CHECK();
         return 0;
@@ -1799,7 +1799,7 @@ int attention_step_fwd(const AttnStepDesc& din, hipStream_t s) {
         const size_t smem = ((size_t)d.A + 2 * Tp + 4 * NT + (size_t)(NT / (d.E / 4)) * d.E + 16 + 32) * sizeof(float);
         T2_REQUIRE(smem <= 160 * 1024, "attention_step (GMM): T_in too long for LDS (%zu bytes)", smem);
         if (smem > 64 * 1024)
-            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_gmm_step_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            T2_TRY_RC(t2_allow_dynamic_lds(reinterpret_cast<const void*>(attention_gmm_step_fwd_kernel), smem));
         hipLaunchKernelGGL(attention_gmm_step_fwd_kernel, dim3(d.B, d.nstreams), dim3(NT), smem, s, d);
         T2_LAUNCH_CHECK();
         return 0;
@@ -1815,8 +1815,7 @@ int attention_step_fwd(const AttnStepDesc& din, hipStream_t s) {
     const size_t smem = attention_fwd_smem(d, d.lsa_pa);
     T2_REQUIRE(smem <= 160 * 1024, "attention_step: T_in too long for LDS (%zu bytes)", smem);
     if (smem > 64 * 1024) {
-        T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_step_fwd_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        T2_TRY_RC(t2_allow_dynamic_lds(reinterpret_cast<const void*>(attention_step_fwd_kernel), smem));
     }
     hipLaunchKernelGGL(attention_step_fwd_kernel, dim3(d.B, d.nstreams), dim3(NT), smem, s, d);
     T2_LAUNCH_CHECK();
@@ -1827,7 +1826,7 @@ int attention_step_fwd(const AttnStepDesc& din, hipStream_t s) {
 template <int MAXI>
 static int launch_lsa_bwd(const AttnBwdDesc& d, size_t smem, hipStream_t s) {
     if (smem > 64 * 1024)
-        T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_lsa_step_bwd_kernel<MAXI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        T2_TRY_RC(t2_allow_dynamic_lds(reinterpret_cast<const void*>(attention_lsa_step_bwd_kernel<MAXI>), smem));
     hipLaunchKernelGGL(attention_lsa_step_bwd_kernel<MAXI>, dim3(d.B, d.nstreams), dim3(NTB), smem, s, d);
     T2_LAUNCH_CHECK();
     return 0;
@@ -1849,7 +1848,7 @@ int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s) {
                              2 * d.A + 12 + 16 + tile) * sizeof(float);
         T2_REQUIRE(smem <= 160 * 1024, "attention_bwd (DCA): T_in too long for LDS (%zu bytes)", smem);
         if (smem > 64 * 1024)
-            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_dca_step_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            T2_TRY_RC(t2_allow_dynamic_lds(reinterpret_cast<const void*>(attention_dca_step_bwd_kernel), smem));
         hipLaunchKernelGGL(attention_dca_step_bwd_kernel, dim3(d.B, d.nstreams), dim3(NTB), smem, s, d);
         T2_LAUNCH_CHECK();
         return 0;
@@ -1862,7 +1861,7 @@ int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s) {
         const size_t smem = ((size_t)d.E + d.A + 2 * Tp + 32 + NTB / 64 + 8 + (NTB / 64) * 16) * sizeof(float);
         T2_REQUIRE(smem <= 160 * 1024, "attention_bwd (GMM): T_in too long for LDS (%zu bytes)", smem);
         if (smem > 64 * 1024)
-            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_gmm_step_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            T2_TRY_RC(t2_allow_dynamic_lds(reinterpret_cast<const void*>(attention_gmm_step_bwd_kernel), smem));
         hipLaunchKernelGGL(attention_gmm_step_bwd_kernel, dim3(d.B, d.nstreams), dim3(NTB), smem, s, d);
         T2_LAUNCH_CHECK();
         return 0;
@@ -1875,10 +1874,10 @@ int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s) {
         const size_t smem_m = (size_t)lsa_mfma_smem(Tmax, d.A, d.E, d.F, d.Kc).total * sizeof(float);
         if (d.A % 32 == 0 && smem_m <= 160 * 1024 && (Tmax + 31) / 32 + d.A / 32 < NTL / 64) {     // matrix-core variant
             if (d.A <= 128) {
-                T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_lsa_step_bwd_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m));
+                T2_TRY_RC(t2_allow_dynamic_lds(reinterpret_cast<const void*>(attention_lsa_step_bwd_mfma_kernel<2>), smem_m));
                 hipLaunchKernelGGL(attention_lsa_step_bwd_mfma_kernel<2>, dim3(d.B, d.nstreams), dim3(NTL), smem_m, s, d);
             } else {
-                T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_lsa_step_bwd_mfma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m));
+                T2_TRY_RC(t2_allow_dynamic_lds(reinterpret_cast<const void*>(attention_lsa_step_bwd_mfma_kernel<4>), smem_m));
                 hipLaunchKernelGGL(attention_lsa_step_bwd_mfma_kernel<4>, dim3(d.B, d.nstreams), dim3(NTL), smem_m, s, d);
             }
             T2_LAUNCH_CHECK();
@@ -1896,11 +1895,11 @@ int attention_step_bwd(const AttnBwdDesc& d, hipStream_t s) {
     const dim3 grid(d.B, d.nstreams, d.nsplit);
     if (d.A <= 128) {
         if (smem > 64 * 1024)
-            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_step_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            T2_TRY_RC(t2_allow_dynamic_lds(reinterpret_cast<const void*>(attention_step_bwd_kernel<2>), smem));
         hipLaunchKernelGGL(attention_step_bwd_kernel<2>, grid, dim3(NTB), smem, s, d);
     } else {
         if (smem > 64 * 1024)
-            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_step_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            T2_TRY_RC(t2_allow_dynamic_lds(reinterpret_cast<const void*>(attention_step_bwd_kernel<4>), smem));
         hipLaunchKernelGGL(attention_step_bwd_kernel<4>, grid, dim3(NTB), smem, s, d);
     }
     T2_LAUNCH_CHECK();

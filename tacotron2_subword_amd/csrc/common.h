@@ -90,3 +90,25 @@ void t2_set_error(const char* fmt, ...);
         int rc__ = (expr);          \
         if (rc__ != 0) return rc__; \
     } while (0)
+
+// Dynamic LDS above 64 KB needs hipFuncSetAttribute once per kernel (and again only for a larger size): the call costs the
+// host tens of microseconds, and the per-step kernels are launched hundreds of times per pass.
+#include <mutex>
+#include <utility>
+#include <vector>
+inline int t2_allow_dynamic_lds(const void* fn, size_t smem) {
+    if (smem <= 64 * 1024) return 0;
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, size_t>> done;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& e : done)
+        if (e.first == fn) {
+            if (e.second >= smem) return 0;
+            T2_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            e.second = smem;
+            return 0;
+        }
+    T2_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    done.emplace_back(fn, smem);
+    return 0;
+}

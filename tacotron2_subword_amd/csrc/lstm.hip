@@ -720,11 +720,7 @@ template <int MT, int BKT> size_t fwd_smem() { return (size_t)(Tile<MT, BKT>::FW
 template <int MT, int BKT> size_t bwd_smem() { return (size_t)Tile<MT, BKT>::BWD_FLOATS * sizeof(float); }
 
 template <typename K>
-int allow_big_lds(K kernel, size_t smem) {
-    if (smem > 64 * 1024)
-        T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    return 0;
-}
+int allow_big_lds(K kernel, size_t smem) { return t2_allow_dynamic_lds(reinterpret_cast<const void*>(kernel), smem); }
 
 // stage width by batch tile count (LDS budget) when every K extent allows it, else 64
 #define LAUNCH_ONE(KERNEL, SMEM, MTV, BKV, GRID, BLOCK, STREAM, DESC)                                 \
