@@ -226,6 +226,15 @@ __global__ __launch_bounds__(NTH) void chain_bwd_lstm_kernel(ChainBwdDesc d) {
 //   G item (s, nt, kp): dx(t) = dg(t) . [W_ih[:,P:] | W_hh]: 64 of the 1536 output columns x one gate block (K = 1024) of
 //       the transposed shadow resident in registers (64 VGPRs); the 8 waves split K, partial tiles summed through LDS.
 // Hops per step: G(t+1) -> A(t) -> P(t) -> G(t).
+//
+// KIND = CHAIN_LSA (LocationSensitiveAttention, attention.py:26-85; the launch path's attention_lsa_step_bwd_mfma_kernel):
+// same items, P and G shared.  The A item keeps, besides the above (processed memory from L2 instead of LDS): the conv
+// weights (zero-padded taps), dloc of the last step with `pad` halo rows on both sides, [w; cum] of two steps, the carried
+// gradient on the cumulative weights, and the d(Wd) / d(Wc) tiles as MFMA accumulators in registers.  Two quantities cross
+// the position splits: the `pad` boundary rows of dloc (stored before the publish of step t+1, read at the start of step t
+// behind the partner's arrival counter) and the softmax dot S = sum_j w_j g_j (one tagged 8-byte write-through store per
+// split and step; the slots are cleared per launch).  Everything that does not need step t's context gradient runs in
+// front of the poll for it (carried gradients, d(Wc) of step t+1, location features, pa and the tanh tile).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int ANC = 64;          // output columns of a G item (attention chain)
 constexpr int AKP = 4;           // K parts = the four gate blocks
@@ -580,8 +589,8 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
             if (tid < 2 * WN) { const int c = tid / WN; wnew[c * TwP + (tid - c * WN)] = in[2]; }
             __syncthreads();
             T2_BSTAMP(11);
-            // work units of this stage over the 8 waves: 0,1 location features of the two position tiles; 2,3,4 the six Q tiles
-            // (two each); 5,6 the two d(Wc) column tiles
+            // work units of this stage over the 8 waves: 0,1 the location features of the two position tiles (32 chained fp32
+            // MFMAs: the long pole); 2..7 one Q tile each (two bf16 MFMAs), 2,3 then a d(Wc) column tile (four)
             if (wave < njt) {
                 // loc[j][f] = sum_{c,k} Wc[f][c][k] wcat[c][j + k - pad]: Toeplitz product on the matrix cores (exact fp32 fma chains)
                 const float* xr = wnew + min(wave * 32 + r, len - 1);
