@@ -705,6 +705,7 @@ bool chain_b_bwd_desc(const Bwd& c, ChainBwdDesc* out) {
     st.dh1 = c.S(c.BL.ddout); st.lddh1 = z.WO;
     st.gates = c.W(c.L.gd); st.c_new = c.W(c.L.cnd); st.c_out = c.W(c.L.cd);
     st.dg = c.S(c.BL.dgd); st.dc_state = c.S(c.BL.dcd);
+    st.dbias_part = c.S(c.BL.partd);                                 // (the launch path's K-split scratch: idle when the chain runs) [MT][4Hd]
     st.site_h = T2_SITE_DEC_H; st.site_c = T2_SITE_DEC_C;
     if (!chain_bwd_plan(d)) return false;
     size_t xb = 0, pb = 0;
@@ -736,6 +737,7 @@ bool chain_a_bwd_desc(const Bwd& c, ChainBwdDesc* out) {
         st.dh1 = c.S(c.BL.ddin) + hoff; st.lddh1 = z.WD;
         st.gates = c.W(s ? c.L.gas : c.L.ga); st.c_new = c.W(s ? c.L.cnas : c.L.cna); st.c_out = c.W(s ? c.L.cas : c.L.ca);
         st.dg = c.S(s ? c.BL.dgas : c.BL.dga); st.dc_state = c.S(s ? c.BL.dcas : c.BL.dca);
+        st.dbias_part = c.S(c.BL.parta) + (size_t)s * 2 * 4 * z.Ha;     // [MT][4Ha] per stream (the launch path's K-split scratch)
         st.site_h = s ? T2_SITE_ATT_H_SUB : T2_SITE_ATT_H; st.site_c = s ? T2_SITE_ATT_C_SUB : T2_SITE_ATT_C;
         st.dctx_a = c.S(c.BL.ddout) + z.Hd + (s ? z.E : 0); st.lddctx_a = z.WO;
         st.dctx_b = c.S(c.BL.ddin) + coff; st.lddctx_b = z.WD;
@@ -1139,7 +1141,10 @@ int t2_decoder_backward(const t2_dims* dims_in, const t2_decoder_weights* w, con
             // h(t-1) pairs with dG(t): drop the first step's rows of dG and the last step's rows of dec_h
             if (z.T > 1) T2_TRY(gemm(with_dgT(matmul_tn(c, DG + (long)z.B * 4 * z.Hd, 4 * z.Hd, c.W(L.dout), z.WO, g->dec.w_hh, z.Hd, 4 * z.Hd, z.Hd, BT - z.B), z.B), sb));
             else T2_TRY(fill_f32(g->dec.w_hh, 0.f, (size_t)4 * z.Hd * z.Hd, sb));
-            T2_TRY(colsum(DG, 4 * z.Hd, BT, 4 * z.Hd, g->dec.b_ih, g->dec.b_hh, cws, sb));
+            if (chain_b) {                                                // the chain summed dG over steps and rows: add the row tiles
+                T2_TRY(batch_sum(cbb.st[0].dbias_part, (z.B + 31) / 32, 4 * z.Hd, g->dec.b_ih, sb));
+                T2_CHECK_HIP(hipMemcpyAsync(g->dec.b_hh, g->dec.b_ih, (size_t)4 * z.Hd * sizeof(float), hipMemcpyDeviceToDevice, sb));
+            } else T2_TRY(colsum(DG, 4 * z.Hd, BT, 4 * z.Hd, g->dec.b_ih, g->dec.b_hh, cws, sb));
         }
         if (chain_a) {
             cab.t0 = t0; cab.t1 = t1;
@@ -1202,7 +1207,10 @@ int t2_decoder_backward(const t2_dims* dims_in, const t2_decoder_weights* w, con
             T2_TRY(gemm(zc, ts));
             T2_TRY(fill_f32(lg.w_hh, 0.f, (size_t)4 * z.Ha * z.Ha, ts));
         }
-        T2_TRY(colsum(DG, 4 * z.Ha, BT, 4 * z.Ha, lg.b_ih, lg.b_hh, cws, ts));
+        if (chain_a) {
+            T2_TRY(batch_sum(cab.st[s].dbias_part, (z.B + 31) / 32, 4 * z.Ha, lg.b_ih, ts));
+            T2_CHECK_HIP(hipMemcpyAsync(lg.b_hh, lg.b_ih, (size_t)4 * z.Ha * sizeof(float), hipMemcpyDeviceToDevice, ts));
+        } else T2_TRY(colsum(DG, 4 * z.Ha, BT, 4 * z.Ha, lg.b_ih, lg.b_hh, cws, ts));
         // prenet (model.py:13-24): dP2 = dG . W_ih[:, :P] ; through ReLU+dropout ; layer 2 ; layer 1
         const float scale = a->prenet_dropout ? 1.0f / (1.0f - dims->p_prenet_dropout) : 1.0f;
         GemmDesc gp = matmul_nn(DG, 4 * z.Ha, lw.w_ih, ldw, dP2, z.P, BT, z.P, 4 * z.Ha);

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_lstm_kernel(ChainBwdDesc d) {
     const int pb = rt * 32 + (tid >> 4), pu = u0 + (tid & 15);       // this thread's (row, unit)
     const bool resumed = d.t1 < d.T;                                  // a later launch of the same pass: state of step t1 is in memory
     float dc = (hasP && resumed && pb < B) ? S.dc_state[(long)pb * H + pu] : 0.f;
+    float bacc[4] = {0.f, 0.f, 0.f, 0.f};                           // this thread's (row, unit): sum over the steps of dg = bias gradient partial
     float pin[7];                                                     // dh1, i, f, g, o, c_new, c_prev of the step to come
     auto load_pin = [&](int t, int tid) {
         const int b = min(rt * 32 + (tid >> 4), B - 1), u = u0 + (tid & 15);
@@ -145,6 +146,8 @@ __global__ __launch_bounds__(NTH) void chain_bwd_lstm_kernel(ChainBwdDesc d) {
             float dgv[4] = {dcn * gg * ig * (1.0f - ig), dcn * in[6] * fg * (1.0f - fg), dcn * ig * (1.0f - gg * gg), dh * tc * og * (1.0f - og)};
             if (pb >= B) { dgv[0] = dgv[1] = dgv[2] = dgv[3] = 0.f; }
             dc = dcn * fg;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bacc[g] += dgv[g];
             if (ep > 0) __syncthreads();                              // (dgL aliases nothing of this phase, but G's partL of the same step follows)
 #pragma unroll
             for (int g = 0; g < 4; ++g) dgL[(g * 32 + (tid >> 4)) * (PU + 4) + (tid & 15)] = dgv[g];
@@ -209,6 +212,21 @@ __global__ __launch_bounds__(NTH) void chain_bwd_lstm_kernel(ChainBwdDesc d) {
         }
     }
     if (hasP && d.t0 > 0 && pb < B) S.dc_state[(long)pb * H + pu] = dc;       // for the launch that continues at t0 - 1
+    if (S.dbias_part) {                                               // bias gradients: fixed-order sum over the row tile's 32 rows
+        __syncthreads();
+        if (hasP) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dgL[(g * 32 + (tid >> 4)) * (PU + 4) + (tid & 15)] = bacc[g];
+        }
+        __syncthreads();
+        if (hasP && tid < 4 * PU) {
+            const int g = tid / PU, u = tid % PU;
+            float sum = 0.f;
+            for (int row = 0; row < 32; ++row) sum += dgL[(g * 32 + row) * (PU + 4) + u];
+            float* o = S.dbias_part + (long)rt * K4 + g * H + u0 + u;
+            *o = resumed ? *o + sum : sum;
+        }
+    }
 }
 
 
@@ -327,6 +345,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
     // ---------------------------------------------------------------- P setup
     const int pb = rt * 32 + (tid >> 4), pu = u0 + (tid & 15);
     float dc = 0.f;
+    float bacc[4] = {0.f, 0.f, 0.f, 0.f};                           // P: sum over the steps of this thread's dg = bias gradient partial
     float pin[7];
     auto load_pin = [&](int t, int tid) {
         const int b = min(rt * 32 + (tid >> 4), B - 1), u = u0 + (tid & 15);
@@ -926,7 +945,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
             if (pb >= B) { dgv[0] = dgv[1] = dgv[2] = dgv[3] = 0.f; }
             dc = dcn * fg;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) dgL[(g * 32 + (tid >> 4)) * (PU + 4) + (tid & 15)] = dgv[g];
+            for (int g = 0; g < 4; ++g) { dgL[(g * 32 + (tid >> 4)) * (PU + 4) + (tid & 15)] = dgv[g]; bacc[g] += dgv[g]; }
             __syncthreads();
             if (wave < 4) {
                 const float* hp = dgL + (wave * 32 + r) * (PU + 4) + hk * 8;
@@ -1014,6 +1033,22 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
     if (tid == 0)
         for (int i = 0; i < 16; ++i) t2_chain_bwd_stamps[wg * 16 + i] += stamp_acc[i];
 #endif
+    // ---------------------------------------------------------------- P epilogue: bias gradients (fixed-order sum over the tile's rows)
+    if (PS.dbias_part) {
+        __syncthreads();
+        if (hasP) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dgL[(g * 32 + (tid >> 4)) * (PU + 4) + (tid & 15)] = bacc[g];
+        }
+        __syncthreads();
+        if (hasP && tid < 4 * PU) {
+            const int g = tid / PU, u = tid % PU;
+            float sum = 0.f;
+            for (int row = 0; row < 32; ++row) sum += dgL[(g * 32 + row) * (PU + 4) + u];
+            PS.dbias_part[(long)rt * K4 + g * H + u0 + u] = sum;
+        }
+        __syncthreads();
+    }
     // ---------------------------------------------------------------- A epilogue: the accumulators leave LDS
     if (hasA) {
         if constexpr (KIND == CHAIN_LSA) {

@@ -239,6 +239,7 @@ struct ChainBwdStream {
     const float* gates; const float* c_new; const float* c_out;   // saved by the forward pass: [T][B][4H], [T][B][H] x2
     float* dg;                            // out: gate pre-activation gradients [T][B][4H]
     float* dc_state;                      // [B][H] dL/dc carried between launches of one pass (chunked ranges)
+    float* dbias_part;                    // [row tiles][4H] sum over steps and the tile's rows of dg: the bias gradients (nullable)
     uint32_t site_h, site_c;
     // attention chain (CHAIN_SMA): gradient sources on ctx(t), saved forward quantities, parameters, outputs
     const float* dctx_a; long lddctx_a;   // dctx_a[(t*B + b)*ld + c]: through the projections / decoder LSTM (dDOUT)
