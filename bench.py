@@ -19,8 +19,9 @@ anything touches a GPU, as the reference's distributed.py:181-200 does — and r
 Rank 0 prints ONE JSON line.  Extra objects (N = 1 unless noted):
   roofline      dominant decoder kernel: algorithmic bytes (or FLOPs) per launch / its average duration, measured with
                 HIP events on the launch stream in one extra (untimed) profiled step
-  fresh_batches the same loop fed like train.py:293-316: every step takes the next of 4 pre-collated ragged host batches
-                through data_utils.batch_to_device (pinned staging, H2D) and parse_batch (two .item() syncs)
+  fresh_batches the same loop fed like train.py:286-316: every step collates the next ragged batch out of its dataset items
+                (data_utils.collate_batch into a page-locked stage), uploads it (batch_to_device) and runs parse_batch +
+                the iteration; no host synchronisation anywhere in it
   fp32          the parity mode (exact fp32 GEMMs everywhere) on the same batch, a short leg
   bf16_error    max-abs difference of mel / gate / alignments between the two modes on the bench batch (eval forward)
   decode        BASELINE configs[3]: inference() at B=32, 1000 decoder steps, stop rule disabled
@@ -225,16 +226,21 @@ def spawn_ranks(n):
     raise SystemExit(rc)
 
 
-def host_batches(T, hp, B, Tin, Tsub, Tn, n, seed):
-    """n ragged host batches in collate_fn's layout (data_utils.py:98-133 dict keys and dtypes), as a loader step yields."""
+def host_items(T, hp, B, Tin, Tsub, Tn, n, seed):
+    """n lists of B dataset items, each item what data_utils.BERTTacotron2Dataset.__getitem__ returns for one utterance
+    (ragged lengths; the CLS vector as a stride-0 view over time, data_utils.py:76-79): what a loader step collates."""
     out = []
     for i in range(n):
         text, il, ilb, mel, gate, ol, sub, pcls, bcls, _ = T.synthetic_batch(hp, B, Tin, Tsub, Tn, seed=seed + 17 * i)
-        d = dict(text=text.numpy(), mel_target=mel.transpose(1, 2).contiguous().numpy(), stop_token=gate.double().numpy(),
-                 bert_embeddings=sub.numpy(), bert_embeddings_cls=bcls, phoneme_embeddings_cls=pcls,
-                 length_mel=ol.double().numpy(), length_text=il.double().numpy(), length_bert=ilb.double().numpy())
-        d["align"] = d["text"]
-        out.append(d)
+        items = []
+        for b in range(B):
+            nt, ns, nm = int(il[b]), int(ilb[b]), int(ol[b])
+            stop = torch.zeros(nm, dtype=torch.float64)
+            stop[-1] = 1.0
+            items.append({"text": text[b, :nt].clone(), "mel_target": mel[b, :, :nm].t().contiguous().numpy(),
+                          "bert_embedding": sub[b, :ns].clone(), "stop_token": stop.numpy(),
+                          "bert_embedding_cls": pcls[b, :1].clone().expand(ns, -1), "phoneme_embedding_cls": pcls[b, :1].clone().expand(nt, -1)})
+        out.append(items)
     return out
 
 
@@ -318,34 +324,46 @@ def main():
     loss_val = float(loss.item())
     extras = world == 1 and not a.no_extras
 
-    # the same loop fed from the host, as train.py:293-316 feeds it: next ragged host batch -> pinned staging -> H2D ->
-    # parse_batch (its two .item() syncs included); 4 pre-collated batches in rotation
+    # the same loop fed from the host, as train.py:286-316 feeds it: every step collates the next model batch out of its B
+    # dataset items (data_utils.collate_batch, straight into a page-locked stage of the ring), uploads it
+    # (data_utils.batch_to_device: non-blocking H2D, CLS rows expanded on the device) and runs parse_batch + the
+    # iteration.  Nothing in it synchronises: the host runs ahead of the GPU exactly as in the resident loop.
     fresh = None
     if extras:
-        hb = host_batches(T, hp, B, Tin, Tsub, Tn, 4, seed=4321)
-        for i in range(2 * len(hb)):                                    # steady state: every host batch through both staging slots of the ring
-            xf, yf = model.parse_batch(D.batch_to_device(hb[i % 4]))
+        hi = host_items(T, hp, B, Tin, Tsub, Tn, 4, seed=4321)
+        ring = D._RING
+
+        def fed_step(i):
+            batch = D.collate_batch(hi[i % 4], ring.get(1))
+            xf, yf = model.parse_batch(D.batch_to_device(batch))
             T.train_step(model, criterion, optimizer, xf, yf, hp, it)
+            return batch
+
+        for i in range(8):                                              # steady state: every batch shape through every stage of the ring
+            hb0 = fed_step(i)
         torch.cuda.synchronize()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+        host_ms = []
         tf0 = time.perf_counter()
-        marks = []
+        evs[0].record()
         for i in range(a.steps):
-            xf, yf = model.parse_batch(D.batch_to_device(hb[i % 4]))
-            marks.append(time.perf_counter())                          # parse_batch's .item() has drained the previous step
-            T.train_step(model, criterion, optimizer, xf, yf, hp, it)
+            h0 = time.perf_counter()
+            fed_step(i)
+            evs[i + 1].record()
+            host_ms.append(round(1e3 * (time.perf_counter() - h0), 2))
         torch.cuda.synchronize()
         dtf = time.perf_counter() - tf0
-        marks.append(time.perf_counter())
-        step_ms = [round(1e3 * (marks[i + 1] - marks[i]), 2) for i in range(len(marks) - 1)]
+        step_ms = [round(evs[i].elapsed_time(evs[i + 1]), 2) for i in range(a.steps)]           # GPU-side: end of step i-1 to end of step i
         med = sorted(step_ms)[len(step_ms) // 2]
         fresh = dict(ms_per_step=round(1e3 * dtf / a.steps, 2), value=round(B * Tn * a.steps / dtf, 1), unit="mel-frames/s",
-                     step_ms=step_ms, ms_per_step_median=med, value_at_median=round(B * Tn / (1e-3 * med), 1),
-                     host_batches=4, bytes_per_batch=int(sum(v.numel() * v.element_size() if torch.is_tensor(v) else v.nbytes
-                                                             for k, v in hb[0].items() if k != "align")),
-                     note="every step: data_utils.batch_to_device (pinned staging + non-blocking H2D of the next ragged host batch) "
-                          "+ parse_batch (.item() syncs) + the training iteration; PCIe-inclusive, never `value`.  The loop "
-                          "drains the queue every step, so a host-side pause (a busy neighbour on the shared host, the Python "
-                          "collector) lands in a step: step_ms lists the steps, ms_per_step is their mean, the median is beside it")
+                     step_ms=step_ms, ms_per_step_median=med, max_over_median=round(max(step_ms) / med, 3), host_ms_per_step=host_ms,
+                     host_batches=4, bytes_uploaded_per_batch=int(sum(v.numel() * v.element_size() if torch.is_tensor(v) else v.nbytes
+                                                                      for k, v in dict.items(hb0) if v is not None and k != "align")
+                                                                  + sum(v.numel() * v.element_size() for v in (hb0.cls_rows or {}).values())),
+                     note="every step: data_utils.collate_batch of the next B ragged items into a page-locked stage + batch_to_device "
+                          "(non-blocking H2D; CLS vectors travel as [B,768] rows and are expanded on the device) + parse_batch (host-side "
+                          "maxima, no .item()) + the training iteration; PCIe-inclusive, never `value`.  step_ms = GPU-side time between "
+                          "the ends of consecutive steps (HIP events), host_ms_per_step = host time to collate + enqueue one step")
 
     # one extra, untimed, profiled step: HIP events around every per-step decoder kernel launch
     roof, kernels = None, None

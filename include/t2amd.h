@@ -42,7 +42,27 @@ enum {
 };
 
 const char* t2_last_error(void);
+/* ABI version: bumped whenever a struct below grows or an argument changes meaning.  2 (round 3): t2_dims carries
+ * score_mask_value[_sub], the layouts carry chain / chain_floats, norm_out of t2_adam_* is 4 floats.  A caller compiled
+ * against another version passes structs of another size: check t2_version() == T2_ABI_VERSION before anything else. */
+#define T2_ABI_VERSION 2
 int t2_version(void);
+/* Sticky status of the persistent kernels of the current device (the reference's nearest analogue: train.py:335-340,
+ * which at least notices a NaN gradient norm).  A chain whose hand-off timed out writes a non-zero code into a word in
+ * page-locked host memory; out_host[0] = that code (0 = fine), read with a plain load: no synchronisation.  While it is
+ * non-zero t2_adam_step changes no parameter (norm_out[2] = 1), and t2_decoder_forward / t2_decoder_infer overwrite the
+ * outputs of an aborted pass with NaN.  Only t2_chain_status_clear resets it. */
+int t2_chain_status(uint32_t* out_host /* [4] */);
+int t2_chain_status_clear(void);
+/* tests: enqueue a kernel that reports `code` exactly as an aborting chain would */
+int t2_debug_report_abort(uint32_t code, void* stream);
+/* tests: occupy `workgroups` CUs (96 KB of LDS each, so no persistent workgroup fits beside one) for `milliseconds` on
+ * `stream` — what a foreign kernel does to a persistent grid; every wait is bounded */
+int t2_debug_occupy(int workgroups, int milliseconds, void* stream);
+/* 1 when this process holds the device's claim on persistent kernels (an flock on /tmp/t2amd-persistent-<pci id>.lock,
+ * taken at the first pass that could use them; env T2_CHAIN_FORCE=1 skips the test).  A process that does not get it runs
+ * the per-step launch path: a persistent grid needs every CU, one process per GPU. */
+int t2_chain_claimed(void);
 /* Arithmetic type of the GEMM operands: 0 = fp32 (exact fp32 fma chains; the parity path, default),
  * 1 = bf16 operands with fp32 accumulation for the large GEMMs (fp32 storage, converted while
  * staging); recurrent state, BatchNorm statistics and attention recurrences stay fp32. */
@@ -344,6 +364,8 @@ int t2_adam_chunks(long numel);
 int t2_adam_step(const t2_adam_tensor* table, int n_tensors, int n_chunks, float* partial, float* norm_out, float max_norm,
                  float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
 int t2_adam_norm(const t2_adam_tensor* table, int n_tensors, int n_chunks, float* partial, float* norm_out, float max_norm, void* stream);
+/* norm_out: FOUR floats — [0] total gradient norm, [1] clip coefficient, [2] 1.0 when the update was skipped because the
+ * device's sticky status word (t2_chain_status) was set, [3] reserved. */
 
 /* In-situ kernel timing for bench.py's roofline figures: after t2_prof_enable(n) the decoder
  * drivers bracket each per-step kernel launch with HIP events on the launch stream (up to n

@@ -150,7 +150,9 @@ class GemmArgs(C.Structure):
 
 
 # every symbol include/t2amd.h declares (tests/test_abi.py checks the library exports them all)
-EXPORTS = ["t2_last_error", "t2_version", "t2_set_precision", "t2_get_precision", "t2_set_overlap", "t2_set_chain", "t2_get_chain", "t2_set_chain_bwd", "t2_set_gemm_staging", "t2_side_join", "t2_decoder_layout_query", "t2_decoder_forward", "t2_decoder_infer",
+ABI_VERSION = 2      # include/t2amd.h T2_ABI_VERSION: struct sizes below match that header and nothing else
+
+EXPORTS = ["t2_last_error", "t2_version", "t2_chain_status", "t2_chain_status_clear", "t2_debug_report_abort", "t2_debug_occupy", "t2_chain_claimed", "t2_set_precision", "t2_get_precision", "t2_set_overlap", "t2_set_chain", "t2_get_chain", "t2_set_chain_bwd", "t2_set_gemm_staging", "t2_side_join", "t2_decoder_layout_query", "t2_decoder_forward", "t2_decoder_infer",
            "t2_decoder_bwd_layout_query", "t2_decoder_backward", "t2_prof_enable", "t2_prof_collect", "t2_adam_chunks", "t2_adam_step", "t2_adam_norm",
            "t2_conv_bn_forward", "t2_conv_bn_backward", "t2_embedding_forward", "t2_embedding_backward",
            "t2_lstm_seq_forward", "t2_lstm_seq_backward", "t2_gemm_ex", "t2_prof_gemm", "t2_colsum", "t2_mask_btc",
@@ -167,6 +169,12 @@ def lib() -> C.CDLL:
                                "there is no CPU fallback for the product path")
         L = C.CDLL(LIB_PATH)
         L.t2_last_error.restype = C.c_char_p
+        if L.t2_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} speaks ABI version {L.t2_version()}, this binding {ABI_VERSION}: rebuild the library "
+                               "(the argument structs differ in size between versions)")
+        L.t2_chain_status.argtypes = [C.POINTER(C.c_uint32)]
+        L.t2_debug_report_abort.argtypes = [C.c_uint32, C.c_void_p]
+        L.t2_debug_occupy.argtypes = [C.c_int, C.c_int, C.c_void_p]
         L.t2_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long,
                               C.c_long, C.c_long, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_size_t,
                               C.c_int, C.c_void_p]

@@ -1,7 +1,10 @@
 // C ABI (include/t2amd.h) and the host-side drivers that sequence the kernels of one decoder
 // pass.  No device allocation, no synchronisation except where the header says so.
+#include <fcntl.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <sys/file.h>
+#include <unistd.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -24,6 +27,7 @@ void t2_set_error(const char* fmt, ...) {
     } while (0)
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 using namespace t2;
@@ -108,6 +112,85 @@ static int stop_poll_get(StopPoll** out) {
     }
     *out = &p;
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sticky status of the persistent kernels, one block per device in PAGE-LOCKED HOST memory that the device writes
+// directly (chain_common.h report_abort) and reads in the optimizer (optim.hip): word 0 = code of the hand-off that
+// timed out (0 = fine).  The host looks at it with a plain load — no copy, no event, no synchronisation — at every
+// entry point of the Python layer and right after its own synchronisation points; nothing clears it but
+// t2_chain_status_clear, so one aborted chain stops every later optimizer step until the caller has seen it.
+// The same block carries this process's CLAIM on the device: a persistent grid needs every CU, so only one process per
+// GPU may launch them (an flock on a per-device file; T2_CHAIN_FORCE=1 skips the test, e.g. for a child process whose
+// parent holds the claim but is idle).
+// ---------------------------------------------------------------------------------------------
+struct StatusBlock { unsigned* host = nullptr; int claim = 0; };        // claim: 0 = not asked yet, 1 = held, -1 = another process holds it
+static StatusBlock g_status[16];
+static std::mutex g_status_mu;
+
+namespace t2 {
+unsigned* chain_sticky_words() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_status_mu);
+    StatusBlock& b = g_status[dev & 15];
+    if (!b.host) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
+        memset(p, 0, 64);
+        b.host = static_cast<unsigned*>(p);
+    }
+    return b.host;
+}
+bool chain_device_claim() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(g_status_mu);
+    StatusBlock& b = g_status[dev & 15];
+    if (b.claim == 0) {
+        b.claim = 1;
+        const char* force = getenv("T2_CHAIN_FORCE");
+        if (!(force && atoi(force) != 0)) {
+            char bus[64] = "";
+            if (hipDeviceGetPCIBusId(bus, sizeof(bus), dev) != hipSuccess) snprintf(bus, sizeof(bus), "dev%d", dev);
+            for (char* c = bus; *c; ++c) if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+            char path[160];
+            snprintf(path, sizeof(path), "/tmp/t2amd-persistent-%s.lock", bus);
+            const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+            if (fd >= 0 && flock(fd, LOCK_EX | LOCK_NB) != 0) {            // held by another process for as long as it lives
+                close(fd);
+                b.claim = -1;
+                fprintf(stderr, "t2amd: another process runs persistent kernels on GPU %s: this process takes the per-step launch path "
+                                "(one process per GPU is the contract; T2_CHAIN_FORCE=1 overrides)\n", bus);
+            }                                                               // (fd stays open: the lock lives as long as the process)
+        }
+    }
+    return b.claim > 0;
+}
+}  // namespace t2
+
+__global__ void status_report_kernel(unsigned* sticky, unsigned code) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(sticky, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// tests: `workgroups` workgroups that each hold a CU's LDS (no persistent workgroup fits next to one) for `ticks` of the
+// 100 MHz realtime counter — what a foreign kernel does to a persistent grid
+__global__ __launch_bounds__(256) void occupy_kernel(unsigned long long ticks, unsigned* sink) {
+    extern __shared__ unsigned hold[];
+    hold[threadIdx.x] = threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    if (hold[(threadIdx.x + 1) & 255] == 0xffffffffu) *sink = 1;            // (keeps the LDS allocation alive)
+}
+// After the persistent kernels of a pass: if one of them aborted (non-zero status word of the pass), its outputs are
+// garbage — overwrite them with NaN so that whatever consumes them (a loss, a vocoder, a file) cannot take them for data.
+__global__ __launch_bounds__(256) void poison_if_aborted_kernel(const unsigned* __restrict__ status, int nwords, float* __restrict__ a, size_t na,
+                                                                float* __restrict__ b, size_t nb) {
+    unsigned any = 0;
+    for (int i = 0; i < nwords; ++i) any |= status[i];
+    if (!any) return;
+    const float qnan = __builtin_nanf("");
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < na; i += (size_t)gridDim.x * 256) a[i] = qnan;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (size_t)gridDim.x * 256) b[i] = qnan;
 }
 
 namespace {
@@ -898,7 +981,38 @@ static std::vector<int> chunk_bounds(int T, bool overlap) {
 extern "C" {
 
 const char* t2_last_error(void) { return g_err; }
-int t2_version(void) { return 1; }
+int t2_version(void) { return T2_ABI_VERSION; }
+int t2_chain_status(uint32_t* out_host) {
+    T2_REQUIRE(out_host, "null argument");
+    const unsigned* w = chain_sticky_words();
+    T2_REQUIRE(w, "t2_chain_status: no status block");
+    for (int i = 0; i < 4; ++i) out_host[i] = __atomic_load_n(w + i, __ATOMIC_RELAXED);
+    return 0;
+}
+int t2_chain_status_clear(void) {
+    unsigned* w = chain_sticky_words();
+    T2_REQUIRE(w, "t2_chain_status_clear: no status block");
+    for (int i = 0; i < 4; ++i) __atomic_store_n(w + i, 0u, __ATOMIC_RELAXED);
+    return 0;
+}
+int t2_debug_report_abort(uint32_t code, void* stream) {
+    unsigned* w = chain_sticky_words();
+    T2_REQUIRE(w, "t2_debug_report_abort: no status block");
+    hipLaunchKernelGGL(status_report_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, code);
+    T2_LAUNCH_CHECK();
+    return 0;
+}
+int t2_chain_claimed(void) { return chain_device_claim() ? 1 : 0; }
+int t2_debug_occupy(int workgroups, int milliseconds, void* stream) {
+    T2_REQUIRE(workgroups >= 1 && workgroups <= 256 && milliseconds >= 1 && milliseconds <= 5000, "t2_debug_occupy: 1..256 workgroups, 1..5000 ms");
+    unsigned* w = chain_sticky_words();
+    T2_REQUIRE(w, "t2_debug_occupy: no status block");
+    const size_t smem = 96 * 1024;                                          // more than half a CU's LDS: one such workgroup per CU, no chain workgroup beside it
+    T2_TRY_RC(t2_allow_dynamic_lds(reinterpret_cast<const void*>(occupy_kernel), smem));
+    hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(256), smem, (hipStream_t)stream, (unsigned long long)milliseconds * 100000ull, w + 8);
+    T2_LAUNCH_CHECK();
+    return 0;
+}
 int t2_set_precision(int mode) {
     T2_REQUIRE(mode == 0 || mode == 1, "t2_set_precision: mode must be 0 (fp32) or 1 (bf16 operands)");
     set_precision(mode);
@@ -1027,7 +1141,12 @@ int t2_decoder_forward(const t2_dims* dims_in, const t2_decoder_weights* w, cons
     }
     if (overlap) T2_TRY(stream_edge(*side, ne++, side->s, c.s));         // join
     // projections over all frames
-    return projection(c, c.P(L.dout), z.WO, BT, a->mel_out, z.M, a->gate_out, 1, true);
+    T2_TRY(projection(c, c.P(L.dout), z.WO, BT, a->mel_out, z.M, a->gate_out, 1, true));
+    if (chain_a || chain_b) {            // an aborted chain must not pass for data (its status words: 0 and 1 of the block)
+        hipLaunchKernelGGL(poison_if_aborted_kernel, dim3(64), dim3(256), 0, c.s, chain_bufs(z, L, a->ws).err, 2, a->mel_out, (size_t)BT * z.M, a->gate_out, (size_t)BT);
+        T2_LAUNCH_CHECK();
+    }
+    return 0;
 }
 
 
@@ -1388,6 +1507,10 @@ int t2_decoder_infer(const t2_dims* dims_in, const t2_decoder_weights* w, const 
         }
     }
     *a->steps_run_host = steps;
+    if (chain) {
+        hipLaunchKernelGGL(poison_if_aborted_kernel, dim3(64), dim3(256), 0, c.s, chain_bufs(z, L, a->ws).err, 1, a->mel_out, (size_t)z.B * T * z.M, a->gate_out, (size_t)z.B * T);
+        T2_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -1052,7 +1052,7 @@ bool chain_plan(ChainDesc& d) {
     }
     const Geo g = geo_of(d, d.UT, d.RT);
     if (g.nL > 256 || g.nA > 256) return false;
-    if (chain_device_cus() < 256) return false;
+    if (chain_device_cus() < 256 || !chain_device_claim()) return false;
     // LDS residency: processed-memory rows first, then (bf16) memory rows, in what the largest stream leaves free
     const int budget = (160 * 1024 - 256) / 4;
     int tmax = 4;
@@ -1086,9 +1086,9 @@ static int chain_launch(const ChainDesc& d, hipStream_t s) {
     const Lds m = lds_of(d, UT, RT, d.lds_Tin, d.lds_Jp, d.lds_Jm);
     const size_t smem = (size_t)m.total * sizeof(float);
     auto kernel = chain_fwd_kernel<UT, RT, 8, KC, KIND, KPN>;
-    T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const Geo g = geo_of(d, UT, RT);
     const int grid = KPN > 0 ? 256 : std::max(g.nL, g.nA);
+    T2_TRY_RC(persistent_prepare(kernel, grid, smem));
     T2_CHECK_HIP(hipMemsetAsync(d.cnt, 0, KPN > 0 ? kChainCntBytes : (size_t)d.NS * g.NRG * 2 * CNT_STRIDE * sizeof(unsigned), s));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(NTH), smem, s, d);
     T2_LAUNCH_CHECK();

@@ -774,7 +774,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                     for (;;) {
                         const u32x2 v2 = __builtin_amdgcn_raw_buffer_load_b64(rsK, soff + (unsigned)(1 - split) * 8u, 0, SC1);
                         if (v2[1] == (unsigned)(t + 1)) { other = __builtin_bit_cast(float, v2[0]); break; }
-                        if (__builtin_amdgcn_s_memrealtime() - t0c > SPIN_TICKS) { if (lane == 0) { atomicMax(d.err, 12u); *abortw = 1; } break; }
+                        if (__builtin_amdgcn_s_memrealtime() - t0c > SPIN_TICKS) { if (lane == 0) { report_abort(d.err, 12u); *abortw = 1; } break; }
                         __builtin_amdgcn_s_sleep(1);
                     }
                 }
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
 
 bool chain_bwd_plan(ChainBwdDesc& d) {
     if (d.H != 1024 || d.B < 1 || d.B > 64) return false;
-    if (chain_device_cus() < 256) return false;
+    if (chain_device_cus() < 256 || !chain_device_claim()) return false;
     if (d.kind == CHAIN_LSTM) return true;
     if ((d.kind != CHAIN_SMA && d.kind != CHAIN_LSA) || d.E != 512 || d.A != 128 || d.NS < 1 || d.NS > 2) return false;
     const bool lsa = d.kind == CHAIN_LSA;
@@ -1136,7 +1136,7 @@ int chain_bwd(const ChainBwdDesc& d, hipStream_t s) {
             T2_CHECK_HIP(hipMemsetAsync(d.CARRYX, 0, chain_bwd_lsa_tagged_bytes(d), s));
         }
         auto launch = [&](auto kernel) -> int {
-            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            T2_TRY_RC(persistent_prepare(kernel, grid, smem));
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(NTH), smem, s, d);
             return 0;
         };
@@ -1151,10 +1151,10 @@ int chain_bwd(const ChainBwdDesc& d, hipStream_t s) {
     const size_t smem = (size_t)(4 + NWV * MT * 32 * PPR) * sizeof(float);
     const int grid = (d.H / GNC) * GKP;
     if (MT == 1) {
-        T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_bwd_lstm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        T2_TRY_RC(persistent_prepare(chain_bwd_lstm_kernel<1>, grid, smem));
         hipLaunchKernelGGL(chain_bwd_lstm_kernel<1>, dim3(grid), dim3(NTH), smem, s, d);
     } else {
-        T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_bwd_lstm_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        T2_TRY_RC(persistent_prepare(chain_bwd_lstm_kernel<2>, grid, smem));
         hipLaunchKernelGGL(chain_bwd_lstm_kernel<2>, dim3(grid), dim3(NTH), smem, s, d);
     }
     T2_LAUNCH_CHECK();

@@ -19,6 +19,17 @@ constexpr int PPR = 40;                    // LDS pitch of a 32-wide partial til
 constexpr int CNT_STRIDE = 32;             // one arrival counter per 128-byte line
 constexpr unsigned long long SPIN_TICKS = 100000000ull;   // 1 s of the 100 MHz realtime counter: every spin is bounded
 
+// Abort reports go to two places: the status word of the pass (in its workspace: which chain of which pass) and the
+// device's STICKY status word, which lives in page-locked host memory (c_api.hip: chain_sticky_words) — the host reads it
+// with a plain load at every entry point and at its own synchronisation points, and the optimizer kernels read it before
+// they touch a parameter.  One copy of the pointer per translation unit, set by persistent_prepare() below.
+static __device__ unsigned* t2_sticky_dev = nullptr;
+__device__ __forceinline__ void report_abort(unsigned* err, unsigned code) {
+    atomicMax(err, code);
+    unsigned* sp = t2_sticky_dev;
+    if (sp) __hip_atomic_store(sp, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - __fdividef(2.0f, __expf(2.0f * x) + 1.0f); }
 __device__ __forceinline__ float fast_sigmoid(float x) { return __fdividef(1.0f, 1.0f + __expf(-x)); }
 
@@ -30,7 +41,7 @@ __device__ __forceinline__ bool poll_counter(const unsigned* cnt, unsigned want,
         const unsigned v = __hip_atomic_load(cnt, T2_RLX_AGENT);
         if (v >= want) return true;
         if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_TICKS) {
-            if ((threadIdx.x & 63) == 0) atomicMax(err, code);
+            if ((threadIdx.x & 63) == 0) report_abort(err, code);
             return false;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -46,7 +57,7 @@ __device__ __forceinline__ bool poll_counters2(const unsigned* cnt0, unsigned wa
         const unsigned v = __hip_atomic_load(p, T2_RLX_AGENT);
         if (__all(v >= want)) return true;
         if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_TICKS) {
-            if (first) atomicMax(err, code);
+            if (first) report_abort(err, code);
             return false;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -60,4 +71,38 @@ __device__ __forceinline__ void publish(unsigned* cnt) {
 }
 
 }  // namespace chain
+
+// Host side, before every persistent launch: dynamic-LDS attribute (cached per device and kernel), the sticky status
+// pointer of this translation unit, and co-residency — a persistent grid makes progress only if ALL its workgroups are
+// resident at once, so a launch whose grid exceeds (workgroups the kernel fits per CU) x (CUs) is refused here instead of
+// spinning into its 1 s time-outs on the device.
+template <class K>
+static int persistent_prepare(K kernel, int grid, size_t smem) {
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    T2_TRY_RC(t2_allow_dynamic_lds(fn, smem));
+    int dev = 0;
+    T2_CHECK_HIP(hipGetDevice(&dev));
+    static std::mutex mu;
+    static std::vector<std::tuple<int, const void*, size_t, int>> seen;       // (device, kernel, LDS bytes) -> workgroups per CU
+    static bool sticky_set[16] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    if (!sticky_set[dev & 15]) {
+        unsigned* sp = chain_sticky_words();
+        T2_REQUIRE(sp, "persistent launch: no status block for device %d", dev);
+        T2_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(chain::t2_sticky_dev), &sp, sizeof(sp)));
+        sticky_set[dev & 15] = true;
+    }
+    int per_cu = -1;
+    for (auto& e : seen)
+        if (std::get<0>(e) == dev && std::get<1>(e) == fn && std::get<2>(e) == smem) per_cu = std::get<3>(e);
+    if (per_cu < 0) {
+        T2_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, chain::NTH, smem));
+        seen.emplace_back(dev, fn, smem, per_cu);
+    }
+    const int cus = chain_device_cus();
+    T2_REQUIRE(per_cu >= 1 && (long)per_cu * cus >= grid,
+               "persistent launch refused: %d workgroups cannot be co-resident (%d per CU x %d CUs with %zu bytes of LDS)", grid, per_cu, cus, smem);
+    return 0;
+}
+
 }  // namespace t2

@@ -91,24 +91,26 @@ void t2_set_error(const char* fmt, ...);
         if (rc__ != 0) return rc__; \
     } while (0)
 
-// Dynamic LDS above 64 KB needs hipFuncSetAttribute once per kernel (and again only for a larger size): the call costs the
-// host tens of microseconds, and the per-step kernels are launched hundreds of times per pass.
+// Dynamic LDS above 64 KB needs hipFuncSetAttribute once per (device, kernel) (and again only for a larger size): the call
+// costs the host tens of microseconds, and the per-step kernels are launched hundreds of times per pass.
 #include <mutex>
-#include <utility>
+#include <tuple>
 #include <vector>
 inline int t2_allow_dynamic_lds(const void* fn, size_t smem) {
     if (smem <= 64 * 1024) return 0;
+    int dev = 0;
+    T2_CHECK_HIP(hipGetDevice(&dev));
     static std::mutex mu;
-    static std::vector<std::pair<const void*, size_t>> done;
+    static std::vector<std::tuple<int, const void*, size_t>> done;
     std::lock_guard<std::mutex> lock(mu);
     for (auto& e : done)
-        if (e.first == fn) {
-            if (e.second >= smem) return 0;
+        if (std::get<0>(e) == dev && std::get<1>(e) == fn) {
+            if (std::get<2>(e) >= smem) return 0;
             T2_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            e.second = smem;
+            std::get<2>(e) = smem;
             return 0;
         }
     T2_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    done.emplace_back(fn, smem);
+    done.emplace_back(dev, fn, smem);
     return 0;
 }

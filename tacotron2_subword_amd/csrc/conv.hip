@@ -294,8 +294,7 @@ int embedding_fwd(const long* ids, const float* table, float* out, int rows, int
 int embedding_bwd(const long* ids, const float* dout, float* dtable, int rows, int D, int vocab, hipStream_t s) {
     const size_t smem = (size_t)rows * sizeof(int);
     T2_REQUIRE(smem <= 150 * 1024, "embedding_bwd: %d tokens do not fit the LDS hit list", rows);
-    if (smem > 64 * 1024)
-        T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(embedding_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    T2_TRY_RC(t2_allow_dynamic_lds(reinterpret_cast<const void*>(embedding_bwd_kernel), smem));
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(vocab), dim3(256), smem, s, ids, dout, dtable, rows, D);
     T2_LAUNCH_CHECK();
     return 0;

@@ -758,11 +758,7 @@ template <bool CONV_A, int WM, int WN, int TM, int TN, int PF>
 int launch_bf16src(const GemmK& g, const __bf16* pa, long lda, const __bf16* pb, long ldb, int splitk, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     const size_t smem = (size_t)2 * (BM + BN) * PK16 * sizeof(__bf16);
-    static bool attr = false;
-    if (!attr) {
-        T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16src_kernel<CONV_A, WM, WN, TM, TN, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = true;
-    }
+    T2_TRY_RC(t2_allow_dynamic_lds(reinterpret_cast<const void*>(gemm_bf16src_kernel<CONV_A, WM, WN, TM, TN, PF>), smem));   // (per device and kernel)
     GemmK gk = g;
     static const int swz = getenv("T2_GEMM_XCD") ? atoi(getenv("T2_GEMM_XCD")) : 1;
     gk.xcd_swizzle = swz && ((g.d.N / BN) * (g.d.M / BM)) % 8 == 0 && (g.d.M / BM) >= 8;
@@ -1011,11 +1007,7 @@ __global__ __launch_bounds__(512) void gemm_bf16src256_kernel(GemmK g, const __b
 template <bool CONV_A>
 int launch_bf16src256(const GemmK& g, const __bf16* pa, long lda, const __bf16* pb, long ldb, int splitk, hipStream_t s) {
     constexpr size_t smem = 128 * 1024;
-    static bool attr = false;
-    if (!attr) {
-        T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16src256_kernel<CONV_A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = true;
-    }
+    T2_TRY_RC(t2_allow_dynamic_lds(reinterpret_cast<const void*>(gemm_bf16src256_kernel<CONV_A>), smem));
     GemmK gk = g;
     const int gx = g.d.N / 256, gy = g.d.M / 256;
     gk.xcd_swizzle = (gx * gy) % 8 == 0 && gy >= 4;
@@ -1241,14 +1233,10 @@ int gemm(const GemmDesc& din, hipStream_t s) {
         else T2_TRY_RC((launch_bf16src<false, 2, 2, 2, 2, 2>(g, pa, lda, pb, ldb, splitk, s)));
     } else if (use_bf16) {
         const size_t smem = (size_t)4 * 128 * PK16 * sizeof(__bf16);
-        static bool attr_set = false;
-        if (!attr_set) {
-            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            T2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            attr_set = true;
-        }
+        T2_TRY_RC(t2_allow_dynamic_lds(reinterpret_cast<const void*>(gemm_bf16_kernel<true, true>), smem));
+        T2_TRY_RC(t2_allow_dynamic_lds(reinterpret_cast<const void*>(gemm_bf16_kernel<true, false>), smem));
+        T2_TRY_RC(t2_allow_dynamic_lds(reinterpret_cast<const void*>(gemm_bf16_kernel<false, true>), smem));
+        T2_TRY_RC(t2_allow_dynamic_lds(reinterpret_cast<const void*>(gemm_bf16_kernel<false, false>), smem));
         if (akc && bkc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), smem, s, g);
         else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, dim3(256), smem, s, g);
         else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(256), smem, s, g);

@@ -231,6 +231,10 @@ size_t chain_exchange_bytes(const ChainDesc& d, size_t* x_bytes, size_t* q_bytes
 constexpr size_t kChainCntBytes = 2 * 4 * 2 * 128; // arrival counters: [NS][row groups <= 4][2] lines of 128 B
 int chain_fwd(const ChainDesc& d, hipStream_t s);
 int chain_device_cus();
+// c_api.hip: the current device's sticky status words (page-locked host memory the device writes directly; the pointer is
+// valid on both sides), and this process's claim on the device's persistent kernels (one process per GPU)
+unsigned* chain_sticky_words();
+bool chain_device_claim();
 
 // Backward (BPTT) of a chain in one launch (chain_bwd.hip)
 struct ChainBwdStream {
@@ -322,6 +326,8 @@ int embedding_bwd(const long* ids, const float* dout, float* dtable, int rows, i
 // ------------------------------------------------------------------ optimizer (optim.hip)
 struct AdamTensor { float* p; const float* g; float* m; float* v; long numel; int first_chunk; int pad_; };   // 48 bytes, mirrors t2_adam_tensor
 int adam_chunks(long numel);
+// norm_out: 4 floats — [0] total norm, [1] clip coefficient, [2] 1 = update skipped (the device's sticky status word was
+// set: an earlier persistent kernel aborted and the gradients are invalid), [3] unused
 int adam_norm(const AdamTensor* table_dev, int n_tensors, int n_chunks, float* partial, float* norm_out, float max_norm, hipStream_t s);
 int adam_step(const AdamTensor* table_dev, int n_tensors, int n_chunks, float* partial, float* norm_out, float max_norm,
               float lr, float b1, float b2, float eps, float wd, int step, hipStream_t s);

@@ -45,8 +45,10 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const AdamTensor* __restrict
     if (threadIdx.x == 0) partial[chunk] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// out[0] = total norm, out[1] = clip coefficient = min(1, max_norm / (norm + 1e-6))   (max_norm <= 0: no clipping)
-__global__ __launch_bounds__(1024) void norm_finish_kernel(const float* __restrict__ partial, int n, float max_norm, float* __restrict__ out) {
+// out[0] = total norm, out[1] = clip coefficient = min(1, max_norm / (norm + 1e-6))   (max_norm <= 0: no clipping),
+// out[2] = 1 when the update must be skipped
+__global__ __launch_bounds__(1024) void norm_finish_kernel(const float* __restrict__ partial, int n, float max_norm, float* __restrict__ out,
+                                                           const unsigned* __restrict__ sticky) {
     __shared__ double red[16];
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 1024) s += (double)partial[i];
@@ -60,6 +62,8 @@ __global__ __launch_bounds__(1024) void norm_finish_kernel(const float* __restri
         const float norm = (float)sqrt(tot);
         out[0] = norm;
         out[1] = max_norm > 0.f ? fminf(1.0f, max_norm / (norm + 1e-6f)) : 1.0f;
+        // an aborted persistent kernel (chain_common.h) left invalid gradients behind: no parameter may move
+        out[2] = (sticky && __hip_atomic_load(sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) ? 1.0f : 0.0f;
     }
 }
 
@@ -70,6 +74,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTensor* __restrict_
     const long off = (long)(chunk - t.first_chunk) * kChunk;
     const long cnt = min((long)kChunk, t.numel - off);
     const float clip = coef ? coef[1] : 1.0f;
+    if (coef && coef[2] != 0.0f) return;                      // gradients invalid (norm_finish_kernel): leave p, m, v untouched
     float* p = t.p + off; const float* g = t.g + off; float* m = t.m + off; float* v = t.v + off;
     auto upd = [&](float& pp, float gg, float& mm, float& vv) {
         gg = gg * clip + wd * pp;
@@ -103,7 +108,7 @@ int adam_chunks(long numel) { return (int)((numel + kChunk - 1) / kChunk); }
 int adam_norm(const AdamTensor* table_dev, int n_tensors, int n_chunks, float* partial, float* norm_out, float max_norm, hipStream_t s) {
     T2_REQUIRE(table_dev && n_tensors >= 1 && n_chunks >= 1 && partial && norm_out, "adam_norm: bad arguments");
     hipLaunchKernelGGL(sumsq_kernel, dim3(n_chunks), dim3(256), 0, s, table_dev, n_tensors, partial);
-    hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(1024), 0, s, partial, n_chunks, max_norm, norm_out);
+    hipLaunchKernelGGL(norm_finish_kernel, dim3(1), dim3(1024), 0, s, partial, n_chunks, max_norm, norm_out, chain_sticky_words());
     T2_LAUNCH_CHECK();
     return 0;
 }

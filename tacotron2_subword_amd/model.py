@@ -127,7 +127,6 @@ class _DecoderFn(torch.autograd.Function):
         pre = cfg.get("pre")
         if pre is not None:                     # Decoder.prologue ran the memory-independent part on its own stream
             torch.cuda.current_stream().wait_event(pre["event"])
-        ops.check_chain_status()                # the previous iteration's persistent kernels ran to completion (no sync: long done)
         for f in list(ops.PRE_PERSISTENT):
             f()
         dp = ops.decoder_forward(W, dims, memory, memory_sub, mem_lengths, sub_lengths, mels,
@@ -174,7 +173,6 @@ class _DecoderFn(torch.autograd.Function):
                 keep.clear()
             torch.autograd.Variable._execution_engine.queue_callback(_join)
         grads = tuple(G.get("decoder." + k) for k in cfg["keys"])
-        ops.queue_chain_status_check(dp)
         ctx.dp = None
         return (dm, dms, None, None, None, None) + grads
 
@@ -297,6 +295,7 @@ class Decoder(nn.Module):
                                                 max_steps=int(self.max_decoder_steps), gate_threshold=float(self.gate_threshold),
                                                 prenet_dropout=self.prenet_dropout, seed=self._next_seed())
         stop = stop.cpu()
+        ops.check_chain_status()                # (the copy above has waited for the whole loop: the status word is final)
         flag = bool((stop >= 0).all())
         n = int(stop.max()) + 1 if flag else steps
         self.last_stop_index = stop
@@ -331,9 +330,16 @@ class BERT_Tacotron2(nn.Module):
     def parse_batch(self, batch):
         """model.py:517-529: 10-tuple -> (x 9-tuple, y 3-tuple) on the GPU."""
         text, il, ilb, mel, gate, ol, sub, pcls, bcls, align = batch
+        # The two maxima (model.py:521-524) are host numbers the loader already knows: data_utils.batch_to_device hands them
+        # over as `host_max`, and lengths that are still host tensors are read before they go up.  Only bare device
+        # tensors cost the reference's two .item() round trips, each of which drains the whole launch queue.
+        hm = getattr(batch, "host_max", None)
+        if hm is None and not (il.is_cuda or ilb.is_cuda or ol.is_cuda):
+            hm = (int(torch.max(torch.cat((il, ilb), 0))), int(torch.max(ol)))
         text, il, ilb = to_gpu(text).long(), to_gpu(il).long(), to_gpu(ilb).long()
-        max_in = int(torch.max(torch.cat((il, ilb), 0)).item())
-        max_out = int(torch.max(ol).item())
+        if hm is None:
+            hm = (int(torch.max(torch.cat((il, ilb), 0)).item()), int(torch.max(ol).item()))
+        max_in, max_out = int(hm[0]), int(hm[1])
         mel, gate, ol, align = to_gpu(mel).float(), to_gpu(gate).float(), to_gpu(ol).long(), to_gpu(align).float()
         return ((text, il, ilb, mel, (max_in, max_out), ol, to_gpu(sub), to_gpu(pcls), to_gpu(bcls)), (mel, gate, align))
 
@@ -428,8 +434,10 @@ class Tacotron2(nn.Module):
 
     def parse_batch(self, batch):
         text, il, mel, gate, ol = batch
+        max_len = None if il.is_cuda else int(torch.max(il))                # host lengths: no device round trip
         text, il = to_gpu(text).long(), to_gpu(il).long()
-        max_len = int(torch.max(il).item())
+        if max_len is None:
+            max_len = int(torch.max(il).item())
         mel, gate, ol = to_gpu(mel).float(), to_gpu(gate).float(), to_gpu(ol).long()
         return ((text, il, mel, max_len, ol), (mel, gate))
 

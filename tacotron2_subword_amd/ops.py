@@ -48,49 +48,40 @@ def rng_normal(seed: int, site: int, n: int, device="cuda") -> torch.Tensor:
 # that makes the launch stream wait for the reductions in flight (a stream-level wait, the host does not block).
 PRE_PERSISTENT = []
 
-# Status words of the persistent kernels of a backward pass, copied to the host without a synchronisation and checked at
-# a later pass once the copy has landed (never blocking the host): an aborted chain (a hand-off that timed out) must not
-# pass silently.  A small pool of page-locked slots is reused (allocating page-locked memory per step is slow).
-_status_pending = []          # [(host int32[4], event)] in launch order
-_status_free = []
+# Sticky status of the persistent kernels (include/t2amd.h t2_chain_status): a chain whose hand-off timed out writes a code
+# into a word in page-locked host memory.  Reading it is a plain load — no copy, no event, no synchronisation — so every
+# entry point below looks at it, and so does whoever has just synchronised for a reason of their own (Decoder.inference
+# after its stop indices arrived, a training loop after loss.item()).  On the device the optimizer reads the same word and
+# changes no parameter while it is set, and the passes overwrite an aborted chain's outputs with NaN; the host-side raise
+# may therefore come one or two (asynchronous) steps late, but nothing is ever trained on or returned as data in between.
+_status_buf = (C.c_uint32 * 4)()
 
 
-_status_calls = 0
-STATUS_CHECK_EVERY = 16       # passes between two status copies (a timed-out hand-off costs seconds: it is noticed either way)
-
-
-def queue_chain_status_check(dp, force: bool = False) -> None:
-    global _status_calls
-    if not dp.ws.is_cuda:
-        return
-    _status_calls += 1
-    if not force and (_status_calls - 1) % STATUS_CHECK_EVERY != 0:
-        return
-    if len(_status_pending) >= 8:                   # nobody has looked for a while: settle the oldest (long finished)
-        _status_pending[0][1].synchronize()
-        check_chain_status()
-    host = _status_free.pop() if _status_free else torch.empty(4, dtype=torch.int32).pin_memory()
-    host.copy_(dp.ws[dp.layout.chain:dp.layout.chain + 4].view(torch.int32), non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(dp.ws.device))
-    _status_pending.append((host, ev))
+def chain_status_words():
+    """(code, 0, 0, 0) of the current device's sticky status block; code 0 = every persistent kernel so far ran through."""
+    L.check(L.lib().t2_chain_status(_status_buf))
+    return tuple(int(v) for v in _status_buf)
 
 
 def check_chain_status(block: bool = False) -> None:
-    """Raises if a previous pass's persistent kernels did not run to completion (status words of t2_decoder_layout.chain).
-    Looks only at passes whose status copy has arrived unless `block`."""
-    while _status_pending:
-        host, ev = _status_pending[0]
-        if block:
-            ev.synchronize()
-        elif not ev.query():
-            return
-        _status_pending.pop(0)
-        st = tuple(int(v) for v in host)
-        _status_free.append(host)
-        if any(st):
-            raise RuntimeError(f"t2amd: a persistent chain kernel of an earlier pass aborted (status words {st}: a hand-off between "
-                               "workgroups timed out — is another process or another persistent kernel using this GPU?); its results are invalid")
+    """Raises if a persistent chain kernel aborted since the last check (and clears the status, so that a caller who
+    catches the error can carry on with the per-step path: _lib.set_chain(False)).  block: synchronise the device first,
+    i.e. cover everything enqueued so far."""
+    if not torch.cuda.is_available():
+        return
+    if block:
+        torch.cuda.synchronize()
+    st = chain_status_words()
+    if any(st):
+        L.check(L.lib().t2_chain_status_clear())
+        raise RuntimeError(f"t2amd: a persistent chain kernel aborted (status {st}: a hand-off between workgroups timed out — is "
+                           "another process or another persistent kernel using this GPU?).  The outputs of that pass were overwritten "
+                           "with NaN and no optimizer step has been applied since")
+
+
+def debug_report_abort(code: int = 99) -> None:
+    """Tests: enqueue a kernel that reports an abort exactly as a timed-out chain would."""
+    L.check(L.lib().t2_debug_report_abort(code, L.stream()))
 
 
 class DecoderPass:
@@ -124,6 +115,7 @@ def decoder_forward(W: L.DecoderWeights, dims: L.Dims, memory, memory_sub, mem_l
                     training: bool, prenet_dropout: bool, seed: int, keep=None, dp: Optional[DecoderPass] = None) -> DecoderPass:
     """Teacher-forced decoder (Decoder.forward, model.py:392-428).  mels: [B,n_mel,T].  dp: a pass whose
     memory-independent part decoder_prologue has already run (the caller has ordered the streams)."""
+    check_chain_status()
     B, Tin, _ = memory.shape
     Tsub, T = (1 if memory_sub is None else memory_sub.shape[1]), mels.shape[2]     # single-stream: no second memory
     phase = 0 if dp is None else 2
@@ -161,6 +153,7 @@ def decoder_backward(W: L.DecoderWeights, P: dict, dims: L.Dims, dp: DecoderPass
     Returns (grads dict keyed like P, d_memory, d_memory_sub).  defer: a list -> the weight gradients are left on the
     library's side stream (d_memory* are complete on the current stream); the tensors that stream still uses are appended
     to the list and the caller must call side_join() before reading a gradient or dropping the list."""
+    check_chain_status()
     single = dims.n_streams == 1
     dev = memory.device
     G = {prefix + k: torch.empty_like(P[prefix + k]) for k in L.decoder_param_keys(dims.attention_kind, single)}
@@ -182,6 +175,7 @@ def decoder_infer(W: L.DecoderWeights, dims: L.Dims, memory, memory_sub, *, max_
                   prenet_dropout: bool, seed: int = 0, poll_every: int = 16, mem_lengths=None, sub_lengths=None):
     """Autoregressive decode (Decoder.inference, model.py:430-492) for any B.
     Returns (DecoderPass sized for max_steps, steps_run, stop_index[B] (int32, -1 = never stopped))."""
+    check_chain_status()
     B, Tin, _ = memory.shape
     Tsub = 1 if memory_sub is None else memory_sub.shape[1]
     dp = DecoderPass(dims, B, max_steps, Tin, Tsub, memory.device)

@@ -75,10 +75,15 @@ class FusedAdam(torch.optim.Adam):
             c = self._fast = dict(n=len(ps), live=live, rows=rows, chunks=chunk, step=steps.pop(), ids=[(id(p), id(self.state[p]["exp_avg"])) for p in ps],
                                   steps=[self.state[p]["step"] for p in ps])
         grads = [p.grad for p in ps]
-        # (a parameter or a moment replaced by load_state_dict / .data assignment invalidates the cache)
-        if any(id(p) != a or id(self.state[p]["exp_avg"]) != b for p, (a, b) in zip(ps, c["ids"])):
+        # a parameter or a moment replaced by load_state_dict invalidates the cache (object identity), and so does storage
+        # that moved under the same object (p.data = ..., model.float()/.to()): the cached addresses are compared with
+        # the live ones every step
+        if any(id(p) != a or id(self.state[p]["exp_avg"]) != b for p, (a, b) in zip(ps, c["ids"])) or \
+                [p.data_ptr() for p in ps] != c["rows"][:, 0].tolist() or \
+                [self.state[p]["exp_avg"].data_ptr() for p in ps] != c["rows"][:, 2].tolist() or \
+                [self.state[p]["exp_avg_sq"].data_ptr() for p in ps] != c["rows"][:, 3].tolist():
             self._fast = None
-            return None
+            return self._fast_step(lib, max_norm)                       # rebuilt from the live addresses (equal by construction: no second retry)
         if not all(g.is_contiguous() and not g.is_sparse and g.dtype == torch.float32 for g in grads):
             raise RuntimeError("FusedAdam: dense contiguous fp32 CUDA parameters only")
         n = c["n"]
@@ -94,7 +99,7 @@ class FusedAdam(torch.optim.Adam):
         slot["event"].record()
         if self._partial is None or self._partial.numel() < c["chunks"] + 2:
             self._partial = torch.empty(c["chunks"] + 2, dtype=torch.float32, device="cuda")
-        norm_out = torch.empty(2, dtype=torch.float32, device="cuda")
+        norm_out = torch.empty(4, dtype=torch.float32, device="cuda")
         lib.t2_adam_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
                                      C.c_float, C.c_float, C.c_int, C.c_void_p]
         b1, b2 = group["betas"]
@@ -112,6 +117,10 @@ class FusedAdam(torch.optim.Adam):
                 loss = closure()
         lib = L.lib()
         lib.t2_adam_chunks.argtypes, lib.t2_adam_chunks.restype = [C.c_long], C.c_int
+        # an aborted persistent kernel the host has already seen: raise before anything else (the kernels below read the same
+        # status word on the device and skip the update on their own when the host has not seen it yet)
+        from . import ops
+        ops.check_chain_status()
         fast = self._fast_step(lib, max_norm)
         if fast is not None:
             return loss if closure is not None else fast
@@ -156,7 +165,7 @@ class FusedAdam(torch.optim.Adam):
         slot["event"].record()
         if self._partial is None or self._partial.numel() < chunk + 2:
             self._partial = torch.empty(chunk + 2, dtype=torch.float32, device="cuda")
-        norm_out = torch.empty(2, dtype=torch.float32, device="cuda")
+        norm_out = torch.empty(4, dtype=torch.float32, device="cuda")
         lib.t2_adam_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
                                      C.c_float, C.c_float, C.c_int, C.c_void_p]
         lib.t2_adam_norm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]

@@ -174,17 +174,103 @@ def test_backward_consumes_chain_activations(env, att):
     assert max(worst.values()) < 0.05, worst
 
 
-def test_aborted_chain_is_reported_at_the_next_pass(env):
-    """The training path checks the persistent kernels' status words of the previous backward when the next pass starts
-    (asynchronous copy, no extra synchronisation): a chain that timed out must raise, not train on garbage."""
+def test_reported_abort_raises_at_every_entry_point(env):
+    """The sticky status word (page-locked host memory the device writes directly): an abort report is seen by the next
+    entry point without any copy or synchronisation of its own, and the raise clears it."""
     L, ops = env
+    ops.check_chain_status(block=True)                               # (whatever earlier tests left behind)
     out, st, (W, P, dims, dp, mem, mems) = _run(env, SMA, 8, 21, 12, 6, chain=True, training=True)
-    ops.check_chain_status(block=True)                               # (whatever earlier tests left pending)
-    ops.queue_chain_status_check(dp, force=True)
-    ops.check_chain_status(block=True)                               # clean pass: nothing raised
-    ops.check_chain_status()                                         # nothing pending: a no-op
-    dp.ws[dp.layout.chain + 3:dp.layout.chain + 4].view(torch.int32).fill_(7)      # as if the backward attention chain had aborted
-    ops.queue_chain_status_check(dp, force=True)
+    assert not any(st) and ops.chain_status_words() == (0, 0, 0, 0)
+    ops.check_chain_status()                                         # clean: a no-op
+    ops.debug_report_abort(7)                                        # as a timed-out hand-off reports
     torch.cuda.synchronize()
+    assert ops.chain_status_words()[0] == 7
     with pytest.raises(RuntimeError, match="persistent chain"):
-        ops.check_chain_status()                                     # the non-blocking form finds the copy landed
+        ops.decoder_forward(W, dims, mem, mems, None, None, torch.zeros(8, 80, 6, device="cuda"), training=False, prenet_dropout=False, seed=1)
+    assert ops.chain_status_words() == (0, 0, 0, 0)                  # the raise cleared it: the caller may carry on
+    ops.check_chain_status(block=True)
+
+
+def _tiny_training_objects():
+    from tacotron2_subword_amd import train as T
+    from tacotron2_subword_amd.hparams import create_hparams
+    hp = create_hparams()
+    hp.distributed_run = False
+    model, opt, crit = T.make_training_objects(hp)
+    model.train()
+    x, y = model.parse_batch(T.synthetic_batch(hp, 8, 24, 16, 40, seed=3))
+    return T, hp, model, opt, crit, x, y
+
+
+def test_reported_abort_skips_the_optimizer_step(env):
+    """an aborted chain's gradients must never reach the parameters.  The optimizer kernels read the
+    sticky word on the device, so the step that follows the abort changes nothing even though the host has not looked
+    yet; the host raises at its next look; after that training carries on."""
+    L, ops = env
+    L.set_precision("bf16"); L.set_chain(True)
+    ops.check_chain_status(block=True)
+    T, hp, model, opt, crit, x, y = _tiny_training_objects()
+    for it in range(2):                                               # Adam state exists, the fast path is warm
+        T.train_step(model, crit, opt, x, y, hp, it)
+    torch.cuda.synchronize()
+    before = {k: v.clone() for k, v in model.state_dict().items() if v.is_floating_point() and "running" not in k}
+    m_before = [opt.state[p]["exp_avg"].clone() for p in model.parameters() if p in opt.state]
+    model.zero_grad()
+    loss = crit(model(x), y, x, 2)[0]
+    loss.backward()
+    torch.cuda._sleep(400_000_000)                                    # (the device is busy for a moment: what follows is enqueued, not yet run)
+    ops.debug_report_abort(12)                                        # "the backward attention chain timed out" — enqueued, the host does not know
+    opt.step(max_norm=hp.grad_clip_thresh)                            # no raise here: the report has not run when the host looks
+    torch.cuda.synchronize()
+    after = model.state_dict()
+    assert all(torch.equal(after[k], v) for k, v in before.items()), "a parameter moved on invalid gradients"
+    assert all(torch.equal(a, b) for a, b in zip(m_before, [opt.state[p]["exp_avg"] for p in model.parameters() if p in opt.state]))
+    with pytest.raises(RuntimeError, match="persistent chain"):
+        T.train_step(model, crit, opt, x, y, hp, 3)                   # the next look (first entry point of the next step)
+    T.train_step(model, crit, opt, x, y, hp, 3)                       # status cleared by the raise: training carries on
+    torch.cuda.synchronize()
+    assert any(not torch.equal(model.state_dict()[k], v) for k, v in before.items())
+    ops.check_chain_status(block=True)
+
+
+@pytest.mark.parametrize("mode", ["no_grad_forward", "inference"])
+def test_chain_starved_of_cus_aborts_loudly(env, mode):
+    """The real failure: a foreign kernel holds CUs, so the persistent grid is never whole; its hand-offs time out after
+    1 s (bounded spins), the grid drains, and (1) the outputs of the pass are NaN, (2) the sticky status is set, (3) the
+    host raises at its next look — under no_grad (GTA, validation) and in Decoder.inference just as in training."""
+    L, ops = env
+    from tacotron2_subword_amd.hparams import create_hparams
+    from tacotron2_subword_amd.model import BERT_Tacotron2
+    from tacotron2_subword_amd import train as T
+    if not L.lib().t2_chain_claimed():
+        pytest.skip("another process holds this GPU's persistent-kernel claim")
+    L.set_precision("bf16"); L.set_chain(True)
+    ops.check_chain_status(block=True)
+    hp = create_hparams()
+    model = BERT_Tacotron2(hp).cuda().eval()
+    b = T.synthetic_batch(hp, 8, 24, 16, 12, seed=4)
+    blocker = torch.cuda.Stream()
+    with torch.cuda.stream(blocker):
+        L.check(L.lib().t2_debug_occupy(96, 2500, blocker.cuda_stream))      # 96 CUs gone for 2.5 s
+    import time
+    time.sleep(0.2)                                                            # the blocker is resident before the pass is enqueued
+    with torch.no_grad():
+        if mode == "no_grad_forward":
+            x, _ = model.parse_batch(b)
+            out = model(x)
+            torch.cuda.synchronize()
+            assert bool(torch.isnan(out[0]).all()) and bool(torch.isnan(out[2]).any())
+            with pytest.raises(RuntimeError, match="persistent chain"):
+                ops.check_chain_status()
+        else:
+            model.decoder.max_decoder_steps, model.decoder.gate_threshold = 16, 2.0
+            with pytest.raises(RuntimeError, match="persistent chain"):
+                model.inference(b[0].cuda(), b[6].cuda(), b[7].cuda(), b[8].cuda())
+    torch.cuda.synchronize()
+    ops.check_chain_status(block=True)                                         # cleared; nothing else pending
+    with torch.no_grad():                                                      # and the device is fine afterwards
+        x, _ = model.parse_batch(b)
+        out = model(x)
+        torch.cuda.synchronize()
+    assert bool(torch.isfinite(out[0]).all())
+    ops.check_chain_status(block=True)
