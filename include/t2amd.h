@@ -320,7 +320,12 @@ typedef struct t2_lstm_seq_args {
     float* h[4]; long ldh;   /* [T,B,*]: row stride ldh (lets two directions share one [T,B,2H] buffer) */
     float* c[4];             /* [T,B,H] saved cells */
     float* gates[4];         /* [T,B,4H] saved activated gates */
+    float* ws; size_t ws_floats;   /* optional exchange space (t2_lstm_seq_chain_ws_floats): with it, H = 256, <= 2 streams,
+                                      B <= 128 and t2_set_chain on, ALL steps run in one persistent launch (csrc/chain_enc.hip,
+                                      exact fp32: the same arithmetic as the per-step kernels up to summation order) */
 } t2_lstm_seq_args;
+/* floats of exchange space the persistent BiLSTM chain needs (backward != 0: its BPTT, handed over as t2_lstm_seq_bwd_args.ws) */
+size_t t2_lstm_seq_chain_ws_floats(int nstreams, int B, int H, int backward);
 int t2_lstm_seq_forward(const t2_lstm_seq_args* a, void* stream);
 typedef struct t2_lstm_seq_bwd_args {
     int nstreams, B, T, H;
@@ -329,7 +334,8 @@ typedef struct t2_lstm_seq_bwd_args {
     const float* dh[4]; long lddh;   /* gradient on the outputs, [T,B,*] with row stride lddh */
     float* dpre[4];                  /* out: gradient wrt pre-activations [T,B,4H] */
     float* dw_hh[4];                 /* out: [4H,H] */
-    float* ws; size_t ws_floats;     /* scratch >= nstreams*(B*H + 8*B*H) + split-K space */
+    float* ws; size_t ws_floats;     /* scratch >= nstreams*(B*H + 8*B*H) + split-K space; also the persistent chain's exchange
+                                        space when >= t2_lstm_seq_chain_ws_floats(nstreams, B, H, 1) */
 } t2_lstm_seq_bwd_args;
 int t2_lstm_seq_backward(const t2_lstm_seq_bwd_args* a, void* stream);
 

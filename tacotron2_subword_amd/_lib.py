@@ -132,7 +132,7 @@ _I4 = C.c_int * 4
 class LstmSeqArgs(C.Structure):
     _fields_ = [("nstreams", C.c_int), ("B", C.c_int), ("T", C.c_int), ("H", C.c_int),
                 ("pre", _P4), ("w_hh", _P4), ("reverse", _I4), ("lengths", C.c_void_p),
-                ("h", _P4), ("ldh", C.c_long), ("c", _P4), ("gates", _P4)]
+                ("h", _P4), ("ldh", C.c_long), ("c", _P4), ("gates", _P4), ("ws", C.c_void_p), ("ws_floats", C.c_size_t)]
 
 
 class LstmSeqBwdArgs(C.Structure):
@@ -155,7 +155,7 @@ ABI_VERSION = 2      # include/t2amd.h T2_ABI_VERSION: struct sizes below match 
 EXPORTS = ["t2_last_error", "t2_version", "t2_chain_status", "t2_chain_status_clear", "t2_debug_report_abort", "t2_debug_occupy", "t2_chain_claimed", "t2_set_precision", "t2_get_precision", "t2_set_overlap", "t2_set_chain", "t2_get_chain", "t2_set_chain_bwd", "t2_set_gemm_staging", "t2_side_join", "t2_decoder_layout_query", "t2_decoder_forward", "t2_decoder_infer",
            "t2_decoder_bwd_layout_query", "t2_decoder_backward", "t2_prof_enable", "t2_prof_collect", "t2_adam_chunks", "t2_adam_step", "t2_adam_norm",
            "t2_conv_bn_forward", "t2_conv_bn_backward", "t2_embedding_forward", "t2_embedding_backward",
-           "t2_lstm_seq_forward", "t2_lstm_seq_backward", "t2_gemm_ex", "t2_prof_gemm", "t2_colsum", "t2_mask_btc",
+           "t2_lstm_seq_forward", "t2_lstm_seq_backward", "t2_lstm_seq_chain_ws_floats", "t2_gemm_ex", "t2_prof_gemm", "t2_colsum", "t2_mask_btc",
            "t2_finalize_bct", "t2_mask_bt", "t2_gemm", "t2_rng_keep_mask", "t2_rng_normal"]
 
 _lib = None
@@ -192,6 +192,7 @@ def lib() -> C.CDLL:
         L.t2_embedding_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.t2_lstm_seq_forward.argtypes = [C.POINTER(LstmSeqArgs), C.c_void_p]
         L.t2_lstm_seq_backward.argtypes = [C.POINTER(LstmSeqBwdArgs), C.c_void_p]
+        L.t2_lstm_seq_chain_ws_floats.argtypes, L.t2_lstm_seq_chain_ws_floats.restype = [C.c_int, C.c_int, C.c_int, C.c_int], C.c_size_t
         L.t2_gemm_ex.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
         L.t2_prof_gemm.argtypes = [C.POINTER(GemmArgs), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p]
         L.t2_colsum.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]

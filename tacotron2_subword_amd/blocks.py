@@ -216,6 +216,10 @@ class _BiLstmFn(torch.autograd.Function):
         a.ldh = 2 * H
         a.c[0], a.c[1] = cells[0].data_ptr(), cells[1].data_ptr()
         a.gates[0], a.gates[1] = gates[0].data_ptr(), gates[1].data_ptr()
+        # exchange space of the persistent chain (one launch for all steps); its own tensor, not the shared scratch: the
+        # two encoders' chains are in flight at the same time on their two streams
+        xws = torch.empty(int(L.lib().t2_lstm_seq_chain_ws_floats(2, B, H, 0)), dtype=torch.float32, device=dev)
+        a.ws, a.ws_floats = L.ptr(xws), xws.numel()
         L.check(L.lib().t2_lstm_seq_forward(C.byref(a), L.stream()))
         ctx.save_for_backward(xt, out, cells, gates, w_ih, w_hh, w_ih_r, w_hh_r)
         ctx.dims = (B, T, E, H)
@@ -229,7 +233,7 @@ class _BiLstmFn(torch.autograd.Function):
         dh = dout.transpose(0, 1).contiguous()                           # [T,B,2H]
         dpre = torch.empty(2, T * B, 4 * H, dtype=torch.float32, device=dev)
         dwhh = torch.empty(2, 4 * H, H, dtype=torch.float32, device=dev)
-        nws = 2 * (B * H + 8 * B * H) + 64 + (8 << 20)
+        nws = max(2 * (B * H + 8 * B * H) + 64, int(L.lib().t2_lstm_seq_chain_ws_floats(2, B, H, 1))) + (8 << 20)
         ws = _scratch(dev, nws)
         a = L.LstmSeqBwdArgs()
         a.nstreams, a.B, a.T, a.H = 2, B, T, H

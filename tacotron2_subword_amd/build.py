@@ -8,7 +8,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OUT = os.path.join(_HERE, "libt2amd.so")
-SOURCES = ["gemm.hip", "lstm.hip", "chain.hip", "chain_bwd.hip", "attention.hip", "conv.hip", "elementwise.hip", "infer.hip", "optim.hip", "c_api.hip"]
+SOURCES = ["gemm.hip", "lstm.hip", "chain.hip", "chain_bwd.hip", "chain_enc.hip", "attention.hip", "conv.hip", "elementwise.hip", "infer.hip", "optim.hip", "c_api.hip"]
 
 
 def _newest(paths):

@@ -177,6 +177,9 @@ __global__ void status_report_kernel(unsigned* sticky, unsigned code) {
 __global__ __launch_bounds__(256) void occupy_kernel(unsigned long long ticks, unsigned* sink) {
     extern __shared__ unsigned hold[];
     hold[threadIdx.x] = threadIdx.x;
+    // the highest vector and accumulation registers: each wave then owns a SIMD's whole register file (512 per lane), so
+    // no wave of any other kernel — whatever its size — fits on a CU this workgroup sits on
+    asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255");
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
     if (hold[(threadIdx.x + 1) & 255] == 0xffffffffu) *sink = 1;            // (keeps the LDS allocation alive)
@@ -1556,6 +1559,17 @@ int t2_lstm_seq_forward(const t2_lstm_seq_args* a, void* stream) {
     T2_REQUIRE(a && a->nstreams >= 1 && a->nstreams <= kMaxLstmStreams, "t2_lstm_seq_forward: bad nstreams");
     T2_REQUIRE(a->H % 64 == 0, "t2_lstm_seq_forward: H=%d must be a multiple of 64", a->H);
     const int B = a->B, T = a->T, H = a->H;
+    // every step of both directions in one persistent launch (chain_enc.hip) when the shape is covered and the caller
+    // gave exchange space; otherwise one launch per step
+    if (g_chain && a->ws && a->ws_floats >= enc_chain_ws_floats(a->nstreams, B, H, 0) && enc_chain_covers(a->nstreams, B, H)) {
+        EncChainDesc d{};
+        d.ND = a->nstreams; d.B = B; d.T = T; d.H = H; d.lengths = a->lengths; d.ldh = a->ldh;
+        for (int s = 0; s < a->nstreams; ++s) {
+            d.pre[s] = a->pre[s]; d.w_hh[s] = a->w_hh[s]; d.reverse[s] = a->reverse[s];
+            d.h[s] = a->h[s]; d.c[s] = a->c[s]; d.gates[s] = a->gates[s];
+        }
+        return enc_chain_fwd(d, a->ws, a->ws_floats, (hipStream_t)stream);
+    }
     for (int step = 0; step < T; ++step) {
         LstmStepDesc d{};
         d.nstreams = a->nstreams; d.B = B; d.H = H; d.drop_p = 0.f;
@@ -1579,6 +1593,8 @@ int t2_lstm_seq_forward(const t2_lstm_seq_args* a, void* stream) {
     return 0;
 }
 
+size_t t2_lstm_seq_chain_ws_floats(int nstreams, int B, int H, int backward) { return enc_chain_ws_floats(nstreams, B, H, backward); }
+
 int t2_lstm_seq_backward(const t2_lstm_seq_bwd_args* a, void* stream) {
     T2_REQUIRE(a && a->nstreams >= 1 && a->nstreams <= kMaxLstmStreams, "t2_lstm_seq_backward: bad nstreams");
     const int B = a->B, T = a->T, H = a->H, ns = a->nstreams;
@@ -1589,7 +1605,17 @@ int t2_lstm_seq_backward(const t2_lstm_seq_bwd_args* a, void* stream) {
     float* gws = part + align4((size_t)ns * ks * B * H);
     T2_REQUIRE(a->ws_floats >= (size_t)(gws - a->ws), "t2_lstm_seq_backward: workspace too small");
     const size_t gws_bytes = (a->ws_floats - (size_t)(gws - a->ws)) * sizeof(float);
-    for (int step = 0; step < T; ++step) {                    // reverse of the processing order
+    const bool chain = g_chain && g_chain_bwd && a->ws_floats >= enc_chain_ws_floats(ns, B, H, 1) && enc_chain_covers(ns, B, H);
+    if (chain) {                                               // whole BPTT in one persistent launch (chain_enc.hip); its exchange space = this scratch
+        EncChainBwdDesc d{};
+        d.ND = ns; d.B = B; d.T = T; d.H = H; d.lddh = a->lddh;
+        for (int i = 0; i < ns; ++i) {
+            d.w_hh[i] = a->w_hh[i]; d.reverse[i] = a->reverse[i]; d.c[i] = a->c[i]; d.gates[i] = a->gates[i];
+            d.dh[i] = a->dh[i]; d.dpre[i] = a->dpre[i];
+        }
+        T2_TRY(enc_chain_bwd(d, a->ws, a->ws_floats, s));
+    }
+    for (int step = 0; step < (chain ? 0 : T); ++step) {      // reverse of the processing order
         LstmBwdPointDesc p{};
         p.nstreams = ns; p.B = B; p.H = H; p.drop_p = 0.f; p.first = step == 0;
         LstmBwdGemmDesc g{};

@@ -82,6 +82,9 @@ __host__ __device__ inline Lds lds_of(const ChainDesc& d, int UT, int RT, int Ti
     if (d.kind != CHAIN_LSTM) {
         m.v = take(d.A + 4); m.ap = take(Tp + 4); m.cum = take(Tp + 4); m.q = take(d.A); m.e = take(Tp + 4); m.an = take(Tp + 4); m.cs = take(EC);
         m.pm = take(Jp * (d.kind == CHAIN_LSA ? d.A + 1 : d.A)); m.mem = take(Jm * EC / 2);    // (LSA reads pm position-major: odd pitch)
+        // decode loop: the projection / prenet workgroups keep their weight fragments (64 KB) in this area instead of the
+        // attention rows, however short the memories are
+        if (d.dec && o - m.pm < 16384) take(16384 - (o - m.pm));
     } else { m.v = m.ap = m.cum = m.q = m.e = m.an = m.cs = m.pm = m.mem = o; }
     m.convw = m.dense = o;
     if (d.kind == CHAIN_LSA) { m.convw = take(d.F * ((2 * d.Kc + 15) & ~15)); m.dense = take(d.A * (d.F + 1)); }   // location layer weights, resident (conv taps zero-padded to a multiple of 16)
@@ -1062,14 +1065,14 @@ bool chain_plan(ChainDesc& d) {
     if (fixed > budget) return false;
     if (d.kind != CHAIN_LSTM) {
         const int EC = d.E / d.CS;
-        int left = budget - fixed;
+        int left = budget - fixed + (d.dec ? 16384 : 0);                        // (dec: `fixed` holds the 64 KB pad the rows will take the place of)
         const int pmp = d.kind == CHAIN_LSA ? d.A + 1 : d.A;
         d.lds_Jp = std::min(tmax, left / pmp); left -= d.lds_Jp * pmp;
         if (d.kind == CHAIN_LSA && (d.lds_Jp < tmax || (d.dec && g.nA > 128))) return false;   // LSA energies read pm from LDS only
         d.lds_Jm = std::min(tmax, left / (EC / 2)) & ~1;
         for (int s = 0; s < d.NS; ++s) { d.Jp[s] = std::min(d.st[s].Tin, d.lds_Jp); d.Jm[s] = std::min(d.st[s].Tin, d.lds_Jm); }
         if (getenv("T2_CHAIN_NO_RESIDENT")) { if (d.kind != CHAIN_LSA) d.Jp[0] = d.Jp[1] = 0; d.Jm[0] = d.Jm[1] = 0; }
-        if (d.dec && (size_t)d.lds_Jp * d.A * 4 + (size_t)d.lds_Jm * EC * 2 < 64 * 1024) return false;     // (projection / prenet fragments live there)
+        if (lds_of(d, d.UT, d.RT, tmax, d.lds_Jp, d.lds_Jm).total > budget) return false;
     }
     return true;
 }

@@ -278,6 +278,30 @@ size_t chain_bwd_lsa_tagged_bytes(const ChainBwdDesc& d);   // LSA: leading part
 size_t chain_bwd_att_exchange_bytes(const ChainBwdDesc& d, size_t* x_bytes, size_t* pbh_bytes, size_t* pbc_bytes, size_t* dqx_bytes, size_t* carry_bytes);
 int chain_bwd(const ChainBwdDesc& d, hipStream_t s);
 
+// Persistent encoder BiLSTM chains (chain_enc.hip): all steps of up to two directions in one launch, exact fp32
+struct EncChainDesc {
+    int ND, B, T, H;                       // directions (streams), batch, steps, hidden units per direction
+    const float* pre[2];                   // [T][B][4H] input-side pre-activations incl. biases
+    const float* w_hh[2];                  // [4H][H]
+    int reverse[2];
+    const int* lengths;                    // [B] or null (unpacked)
+    float* h[2]; long ldh;                 // h[s][(t*B + b)*ldh + u]
+    float* c[2]; float* gates[2];          // [T][B][H], [T][B][4H]
+    float* X; unsigned* cnt; unsigned* err;   // filled by enc_chain_fwd from the exchange space
+};
+struct EncChainBwdDesc {
+    int ND, B, T, H;
+    const float* w_hh[2]; int reverse[2];
+    const float* c[2]; const float* gates[2];
+    const float* dh[2]; long lddh;         // gradient on the outputs: dh[s][(t*B + b)*lddh + u]
+    float* dpre[2];                        // out: [T][B][4H]
+    float* X; float* PB; unsigned* cnt; unsigned* err;
+};
+bool enc_chain_covers(int ND, int B, int H);
+size_t enc_chain_ws_floats(int ND, int B, int H, int backward);
+int enc_chain_fwd(EncChainDesc d, float* ws, size_t ws_floats, hipStream_t s);
+int enc_chain_bwd(EncChainBwdDesc d, float* ws, size_t ws_floats, hipStream_t s);
+
 // ------------------------------------------------------------------ decode-step tail (infer.hip)
 // projection + stop rule of step t and both prenets of step t+1, one workgroup per batch item
 struct StepTailDesc {

@@ -215,6 +215,61 @@ def test_bilstm_vs_oracle(env, packed):
         assert rel(q.grad, p.grad) < 3e-4, k
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("packed", [True, False])
+@pytest.mark.parametrize("B,T", [(5, 11), (64, 23), (33, 40), (128, 9)])
+def test_bilstm_persistent_chain_vs_oracle(env, B, T, packed, mode):
+    """The encoder BiLSTM at the reference's size (H = 256, model.py:93-112) runs ALL its steps, both directions, in one
+    persistent launch forward and one backward (csrc/chain_enc.hip, exact fp32 in both precision modes; the hoisted input
+    GEMM follows the mode).  Against the oracle's nn.LSTM restatement and against the per-step launch path."""
+    L, blocks, ops = env
+    if not L.lib().t2_chain_claimed():
+        pytest.skip("another process holds this GPU's persistent-kernel claim")
+    g = torch.Generator().manual_seed(B * 100 + T)
+    E = 512
+    lstm = torch.nn.LSTM(E, E // 2, 1, batch_first=True, bidirectional=True)
+    x = torch.randn(B, T, E, generator=g, requires_grad=True)
+    lengths = None
+    if packed:
+        lengths = torch.randint(1, T + 1, (B,), generator=g).sort(descending=True).values
+        lengths[0] = T
+    P = {"l." + k: v for k, v in lstm.named_parameters()}
+    out = O.bilstm(x, lengths, P, "l")
+    R = torch.randn(out.shape, generator=g)
+    (out * R).sum().backward()
+    import copy
+    res = {}
+    L.set_precision(mode)
+    try:
+        for chain in (True, False):
+            L.set_chain(chain)
+            dl = copy.deepcopy(lstm).cuda()
+            dl.zero_grad()
+            xd = x.detach().cuda().requires_grad_(True)
+            y = blocks.bilstm(xd, None if lengths is None else lengths.cuda(), dl)
+            (y * R.cuda()).sum().backward()
+            torch.cuda.synchronize()
+            res[chain] = (y.detach(), xd.grad, {k: q.grad for k, q in dl.named_parameters()})
+    finally:
+        L.set_precision("f32"); L.set_chain(True)
+    ops.check_chain_status(block=True)
+    tol_y, tol_g = (1e-4, 3e-4) if mode == "f32" else (3e-2, 3e-2)     # bf16 mode: the input GEMM's operands are bf16
+    y, dx, gw = res[True]
+    assert maxabs(y, out) < tol_y
+    assert rel(dx, x.grad) < tol_g
+    for k, p in lstm.named_parameters():
+        assert rel(gw[k], p.grad) < tol_g, k
+    # chain vs launches: the same arithmetic up to summation order (and the accurate exp in both)
+    y0, dx0, gw0 = res[False]
+    tol_c = 1e-4 if mode == "f32" else 2e-3       # (bf16 mode: the GEMMs behind dpre round their operands: 1e-7 apart can become one bf16 ulp)
+    assert maxabs(y, y0) < 2e-5 and rel(dx, dx0) < tol_c
+    for k in gw:
+        assert rel(gw[k], gw0[k]) < tol_c, k
+    if packed:                                                        # frames past an item's length are exactly zero
+        for b in range(B):
+            assert not y[b, int(lengths[b]):].any()
+
+
 def test_fused_adam_matches_clip_plus_torch_adam():
     """optim.FusedAdam.step(max_norm) vs torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step over odd-sized tensors,
     several steps, with and without clipping being active; state_dicts interchange."""

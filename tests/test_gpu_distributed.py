@@ -77,7 +77,8 @@ def _worker_nccl(rank, world, port, q):
     all_reduce(async_op=True) path of the wrapper on a real RCCL stream, in the bf16 mode bench.py runs, persistent
     chain kernels and side streams included.  With one rank the averaged gradient must equal the local one."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      T2_CHAIN_FORCE="1")    # the parent (pytest) may hold this GPU's persistent-kernel claim; it is idle while this runs
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=rank, world_size=world)
@@ -116,6 +117,7 @@ def _worker_nccl(rank, world, port, q):
             for k in want:
                 err = float((got[k] - want[k]).abs().max()) / max(float(want[k].abs().max()), 1e-6)
                 assert err < 1e-5, (step, k, err)
+        assert L.lib().t2_chain_claimed() == 1 and L.get_chain()               # the persistent chains really ran in this process
         r = reduce_tensor(torch.tensor([3.0], device="cuda"), world)          # train.py:23-27
         assert float(r) == 3.0
         q.put((rank, "ok", ""))
