@@ -408,7 +408,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 for (int g = 0; g < 4; ++g) pre[sl][g] = pre_next[sl][g];
             T2_CSTAMP(15);
             if (!EARLY || !hasA) {                  // (an attention item's workgroup has polled this counter in its A phase)
-                if (wave == 0 && !poll_counter(cntH_L, ep * (unsigned)G.NUG, d.err, 1u) && lane == 0) *abortw = 1;
+                if (wave == 0 && !poll_counter(cntH_L, ep, (unsigned)G.NUG, d.err, 1u) && lane == 0) *abortw = 1;
                 __syncthreads();
                 if (*abortw) return;
             }
@@ -416,8 +416,8 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             if (EARLY) issue_h(t - 1);
             if (KC > 0) {
                 if (wave == 0) {
-                    bool ok = poll_counter(cntC_L, ep * nA_per_step, d.err, 2u);
-                    if (ok && DEC) ok = poll_counter(d.cnt + (size_t)(10 + ls) * CNT_STRIDE, ep * (unsigned)(d.P / 16), d.err, 11u);   // prenet output of this step
+                    bool ok = poll_counter(cntC_L, ep, nA_per_step, d.err, 2u);
+                    if (ok && DEC) ok = poll_counter(d.cnt + (size_t)(10 + ls) * CNT_STRIDE, ep, (unsigned)(d.P / 16), d.err, 11u);   // prenet output of this step
                     if (!ok && lane == 0) *abortw = 1;
                 }
                 __syncthreads();
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 }
             }
             T2_CSTAMP(4);
-            publish(cntH_L);
+            publish(cntH_L, (unsigned)ug);
             T2_CSTAMP(5);
             // saved activations: issued here, in the slack before the next poll is answered (issuing scattered stores costs
             // the wave hundreds of cycles; behind the next phase's loads they sat on the critical path: measured +1.2 us/step)
@@ -565,8 +565,8 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 for (int j = tid; j < Tin; j += NTH) locL[j * F1 + F] = 0.f;         // pad column (K rounded up to even)
             }
             if (wave == 0) {                          // h_t of the item's row group, and (one request) of the L item's for step t+1
-                const bool ok = (EARLY && hasL && more) ? poll_counters2(cntH_A, (ep + 1) * (unsigned)G.NUG, cntH_L, (ep + 1) * (unsigned)G.NUG, d.err, 3u)
-                                                        : poll_counter(cntH_A, (ep + 1) * (unsigned)G.NUG, d.err, 3u);
+                const bool ok = (EARLY && hasL && more) ? poll_counters2(cntH_A, ep + 1, (unsigned)G.NUG, cntH_L, ep + 1, (unsigned)G.NUG, d.err, 3u)
+                                                        : poll_counter(cntH_A, ep + 1, (unsigned)G.NUG, d.err, 3u);
                 if (!ok && lane == 0) *abortw = 1;
             }
             __syncthreads();
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                     xout + (unsigned)as * G.xs_bytes + (unsigned)(((kt * G.MT + ab_ / 32) * 64 + (pc & 1) * 32 + (ab_ & 31)) * 16), 0, SC1);
             }
             T2_CSTAMP(11);
-            publish(cntC_A);
+            publish(cntC_A, (unsigned)(arow * d.CS + part));
             T2_CSTAMP(12);
             store_A_saved(t, tid);
         }
@@ -830,8 +830,8 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                     const int stw = kgw < sg0 ? 0 : 1;
                     const bool isc = !fd && kgw - stw * sg0 >= H;
                     const unsigned* cp = fd ? cntD : d.cnt + (size_t)(2 * stw + (isc ? 1 : 0)) * CNT_STRIDE;
-                    const unsigned want = fd ? ep * (unsigned)(Hd / DU) : isc ? (ep + 1) * (unsigned)(B * d.CS) : (ep + 1) * (unsigned)G.NUG;
-                    if (!poll_counter(cp, want, d.err, 12u) && lane == 0) *abortw = 1;
+                    const unsigned wsteps = fd ? ep : ep + 1, wprod = fd ? (unsigned)(Hd / DU) : isc ? (unsigned)(B * d.CS) : (unsigned)G.NUG;
+                    if (!poll_counter(cp, wsteps, wprod, d.err, 12u) && lane == 0) *abortw = 1;
                 }
                 T2_CSTAMP(1);
                 const int kg = wave * (DNW * 32);
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                         (unsigned)((t & 1) * (Hd / 16) * 1024) + (unsigned)((((du0 >> 4) * 64) + ((du0 >> 3) & 1) * 32 + tid) * 16 + ((du0 & 7) >> 2) * 8), 0, SC1);
                 }
                 T2_CSTAMP(6);
-                publish(cntD);
+                publish(cntD, (unsigned)wg);
             }
             // =================================================================================== P1(t): mel / gate projections + stop rule (model.py:382-388, 461-480)
             if (hasP1) {
@@ -897,7 +897,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 const bool from_d = kg < Hd;
                 const int st = kg < Hd + Ee ? 0 : 1;
                 if (!poll_counter(from_d ? cntD : d.cnt + (size_t)(2 * st + 1) * CNT_STRIDE,
-                                  from_d ? (ep + 1) * (unsigned)(Hd / DU) : (ep + 1) * (unsigned)(B * d.CS), d.err, 13u) && lane == 0) *abortw = 1;
+                                  ep + 1, from_d ? (unsigned)(Hd / DU) : (unsigned)(B * d.CS), d.err, 13u) && lane == 0) *abortw = 1;
                 const int lk = from_d ? kg : H + (kg - Hd - st * Ee);                // ctx sits behind h in a stream's fragments
                 const unsigned base = from_d ? (unsigned)((t & 1) * (Hd / 16) * 1024) : xcur + (unsigned)st * G.xs_bytes;
                 f32x4 accp[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -949,11 +949,11 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                     for (int j = 0; j < 4; ++j) { o[j] = (__bf16)lo[j]; o[4 + j] = (__bf16)hi[j]; }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsM, (unsigned)(((t & 1) * 8 + p1g) * 1024 + lane * 16), 0, SC1);
                 }
-                publish(cntM);
+                publish(cntM, (unsigned)p1g);
             }
             // =================================================================================== P2(t): both prenet layers of frame t+1 (model.py:13-24, 470-471)
             if (hasP2 && t + 1 < d.T) {
-                if (wave == 0 && !poll_counter(cntM, (ep + 1) * (unsigned)((Mm + 1 + 15) / 16), d.err, 14u) && lane == 0) *abortw = 1;
+                if (wave == 0 && !poll_counter(cntM, ep + 1, (unsigned)((Mm + 1 + 15) / 16), d.err, 14u) && lane == 0) *abortw = 1;
                 __syncthreads();
                 if (*abortw) return;
                 const RngKey k1 = rng_key(d.seed, d.psite1[p2s]), k2 = rng_key(d.seed, d.psite2[p2s]);
@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsX,
                         xcur + (unsigned)p2s * G.xs_bytes + (unsigned)((((H + Ee) / 16 + p2c) * G.MT) * 1024 + lane * 16), 0, SC1);
                 }
-                publish(d.cnt + (size_t)(10 + p2s) * CNT_STRIDE);
+                publish(d.cnt + (size_t)(10 + p2s) * CNT_STRIDE, (unsigned)p2c);
             }
         }
     }

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_lstm_kernel(ChainBwdDesc d) {
             float dh = in[0];
             if (ep > 0 || resumed) {
                 if (ep > 0) {                                         // (a resumed launch finds step t1's partials complete)
-                    if (wave == 0 && !poll_counter(cntG_wait, ep * (unsigned)GKP, d.err, 5u) && lane == 0) *abortw = 1;
+                    if (wave == 0 && !poll_counter(cntG_wait, ep, (unsigned)GKP, d.err, 5u) && lane == 0) *abortw = 1;
                     __syncthreads();
                     if (*abortw) return;
                 }
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_lstm_kernel(ChainBwdDesc d) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsX,
                     (unsigned)(t & 1) * (unsigned)(KT * MT * 1024) + (unsigned)((((wave * H + u0) / 16) * MT + rt) * 1024 + lane * 16), 0, SC1);
             }
-            publish(cntP_mine);
+            publish(cntP_mine, (unsigned)(((u0 % (H / 2)) / PU) * MT + rt));
             {   // fp32 dg(t) rows for the weight-gradient GEMMs, then next step's operands (cold HBM rows) behind them
                 const int b = rt * 32 + (tv >> 4), u = u0 + (tv & 15);
                 if (b < B) {
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_lstm_kernel(ChainBwdDesc d) {
         }
         // ======================================================================================= G(t)
         if (hasG && t > 0) {                                          // (dx(0) feeds nothing)
-            if (wave == 0 && !poll_counter(cntP, (ep + 1) * nP_half, d.err, 6u) && lane == 0) *abortw = 1;
+            if (wave == 0 && !poll_counter(cntP, ep + 1, nP_half, d.err, 6u) && lane == 0) *abortw = 1;
             __syncthreads();
             if (*abortw) return;
             f32x16 acc[MT];
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_lstm_kernel(ChainBwdDesc d) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sum), rsP,
                     (unsigned)(t & 1) * pb_half + (unsigned)((((kp * (H / PU) + ugo) * MT + m) * 32 + row) * PU + (c4 % PU)) * 4u, 0, SC1);
             }
-            publish(cntG_mine);
+            publish(cntG_mine, (unsigned)kp);
         }
     }
     if (hasP && d.t0 > 0 && pb < B) S.dc_state[(long)pb * H + pu] = dc;       // for the launch that continues at t0 - 1
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) in[i] = ain[i];
             if (ep > 0) {
-                if (wave == 0 && !poll_counter(CNT(2 + as), ep * (unsigned)(NTC * AKP), d.err, 7u) && lane == 0) *abortw = 1;
+                if (wave == 0 && !poll_counter(CNT(2 + as), ep, (unsigned)(NTC * AKP), d.err, 7u) && lane == 0) *abortw = 1;
                 __syncthreads();
                 if (*abortw) return;
             }
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q4), rsQ, (unsigned)((((as * 2 + split) * B + ab_) * A + tid * 4) * 4), 0, SC1);
             }
             T2_BSTAMP(3);
-            publish(CNT(4 + as * 2 + ab_ / 32));
+            publish(CNT(4 + as * 2 + ab_ / 32), (unsigned)((ab_ & 31) * 2 + split));
             T2_BSTAMP(4);
             if (tid < A) AS.dq_out[((long)t * B + ab_) * 2 * A + split * A + tid] = dqoL[tid];
             if (t > d.t0) load_ain(t - 1, tid);
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
             // other split, gradient carried to w_t / cum_t, d(Wc) of step t+1, location features and tanh tile of step t.
             // ------------------------------------------------------------------------------------------------------------
             if (ep > 0) {
-                if (wave == 0 && !poll_counter(CNT(4 + as * 2 + ab_ / 32), ep * (unsigned)(min(32, B - (ab_ / 32) * 32) * 2), d.err, 11u) && lane == 0) *abortw = 1;
+                if (wave == 0 && !poll_counter(CNT(4 + as * 2 + ab_ / 32), ep, (unsigned)(min(32, B - (ab_ / 32) * 32) * 2), d.err, 11u) && lane == 0) *abortw = 1;
                 __syncthreads();
                 if (*abortw) return;
                 if (tid < pad * (F / 4)) {                                // the partner's `pad` rows next to the boundary
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
             // ------------------------------------------------------------------------------------------------------------
             T2_BSTAMP(13);
             if (ep > 0) {
-                if (wave == 0 && !poll_counter(CNT(2 + as), ep * (unsigned)(NTC * AKP), d.err, 7u) && lane == 0) *abortw = 1;
+                if (wave == 0 && !poll_counter(CNT(2 + as), ep, (unsigned)(NTC * AKP), d.err, 7u) && lane == 0) *abortw = 1;
                 __syncthreads();
                 if (*abortw) return;
             } else __syncthreads();
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                     (unsigned)(((((t & 1) * d.NS + as) * B + ab_) * 2 + split) * pad * F + row * F + f4) * 4u, 0, SC1);
             }
             T2_BSTAMP(3);
-            publish(CNT(4 + as * 2 + ab_ / 32));
+            publish(CNT(4 + as * 2 + ab_ / 32), (unsigned)((ab_ & 31) * 2 + split));
             T2_BSTAMP(4);
             if (tid < A) AS.dq_out[((long)t * B + ab_) * 2 * A + split * A + tid] = dqoL[tid];
             if (t > d.t0) load_ain(t - 1, tid);
@@ -891,8 +891,8 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
 #pragma unroll
             for (int i = 0; i < 7; ++i) in[i] = pin[i];
             if (wave == 0) {
-                bool ok = poll_counter(CNT(4 + ps * 2 + rt), (ep + 1) * (unsigned)(min(32, B - rt * 32) * 2), d.err, 8u);
-                if (ok && ep > 0) ok = poll_counter(CNT(8 + ps * 16 + u0 / ANC), ep * (unsigned)AKP, d.err, 9u);
+                bool ok = poll_counter(CNT(4 + ps * 2 + rt), ep + 1, (unsigned)(min(32, B - rt * 32) * 2), d.err, 8u);
+                if (ok && ep > 0) ok = poll_counter(CNT(8 + ps * 16 + u0 / ANC), ep, (unsigned)AKP, d.err, 9u);
                 if (!ok && lane == 0) *abortw = 1;
             }
             __syncthreads();
@@ -957,7 +957,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                     (unsigned)((t & 1) * d.NS + ps) * xs + (unsigned)((((wave * H + u0) / 16) * MT + rt) * 1024 + lane * 16), 0, SC1);
             }
             T2_BSTAMP(6);
-            publish(CNT(ps));
+            publish(CNT(ps), (unsigned)(wg % nPs));
             T2_BSTAMP(7);
             {
                 const int b = rt * 32 + (tv >> 4), u = u0 + (tv & 15);
@@ -970,7 +970,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
         }
         // ======================================================================================= G(t)
         if (hasG && t > 0) {
-            if (wave == 0 && !poll_counter(CNT(gs), (ep + 1) * (unsigned)nPs, d.err, 10u) && lane == 0) *abortw = 1;
+            if (wave == 0 && !poll_counter(CNT(gs), ep + 1, (unsigned)nPs, d.err, 10u) && lane == 0) *abortw = 1;
             __syncthreads();
             if (*abortw) return;
             T2_BSTAMP(8);
@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                 }
             }
             T2_BSTAMP(9);
-            publish(nt < NTC ? CNT(2 + gs) : CNT(8 + gs * 16 + (nt - NTC)));
+            publish(nt < NTC ? CNT(2 + gs) : CNT(8 + gs * 16 + (nt - NTC)), (unsigned)(nt < NTC ? kp * NTC + nt : kp));
             T2_BSTAMP(10);
         }
     }

@@ -16,7 +16,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int NTH = 512, NWV = 8;
 constexpr int SC1 = 16;                    // buffer-instruction cache policy bit: sc1 (agent scope, bypass L1 / write through)
 constexpr int PPR = 40;                    // LDS pitch of a 32-wide partial tile row (conflict-free fixed-order reads)
-constexpr int CNT_STRIDE = 32;             // one arrival counter per 128-byte line
+constexpr int NSH = kCntShards;            // shards of an arrival counter
+constexpr int CNT_LINE = 32;               // unsigned words per 128-byte line
+constexpr int CNT_STRIDE = NSH * CNT_LINE; // words per (sharded) arrival counter
 constexpr unsigned long long SPIN_TICKS = 100000000ull;   // 1 s of the 100 MHz realtime counter: every spin is bounded
 
 // Abort reports go to two places: the status word of the pass (in its workspace: which chain of which pass) and the
@@ -33,13 +35,23 @@ __device__ __forceinline__ void report_abort(unsigned* err, unsigned code) {
 __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - __fdividef(2.0f, __expf(2.0f * x) + 1.0f); }
 __device__ __forceinline__ float fast_sigmoid(float x) { return __fdividef(1.0f, 1.0f + __expf(-x)); }
 
-// one wave polls one counter; all lanes read the same word (a single request), so the branch is wave-uniform
-__device__ __forceinline__ bool poll_counter(const unsigned* cnt, unsigned want, unsigned* err, unsigned code) {
-    if (want == 0) return true;
+// Arrival counters are SHARDED: producer i of a group adds to shard i % NSH, each shard on a 128-byte line of its own; the
+// polling wave reads all shards in one request (lane -> shard lane % NSH) and is satisfied when every shard has the arrivals
+// of `steps` steps.  Why: with one word per group the 64-128 adds of a step serialise on one line while 64-128 workgroups
+// poll it; scripts/persist_probe.hip (chain A's traffic pattern, no arithmetic): 9.7 us per two-hop step with one word,
+// 8.1 with 4 shards, 7.1 with 16 (replicas on top: 7.0).
+// producers of shard sh among `P` producers numbered 0..P-1
+__device__ __forceinline__ unsigned shard_share(unsigned P, unsigned sh) { return (P + (unsigned)NSH - 1u - sh) / (unsigned)NSH; }
+// one wave polls one counter: `steps` steps of `P` producers each
+__device__ __forceinline__ bool poll_counter(const unsigned* cnt, unsigned steps, unsigned P, unsigned* err, unsigned code) {
+    if (steps == 0) return true;
+    const unsigned sh = threadIdx.x & (NSH - 1);
+    const unsigned* p = cnt + sh * CNT_LINE;
+    const unsigned want = steps * shard_share(P, sh);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
-        const unsigned v = __hip_atomic_load(cnt, T2_RLX_AGENT);
-        if (v >= want) return true;
+        const unsigned v = __hip_atomic_load(p, T2_RLX_AGENT);
+        if (__all(v >= want)) return true;
         if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_TICKS) {
             if ((threadIdx.x & 63) == 0) report_abort(err, code);
             return false;
@@ -47,27 +59,29 @@ __device__ __forceinline__ bool poll_counter(const unsigned* cnt, unsigned want,
         __builtin_amdgcn_s_sleep(2);
     }
 }
-// two counters in one request: lane 0 reads cnt0, every other lane cnt1
-__device__ __forceinline__ bool poll_counters2(const unsigned* cnt0, unsigned want0, const unsigned* cnt1, unsigned want1, unsigned* err, unsigned code) {
-    const bool first = (threadIdx.x & 63) == 0;
-    const unsigned* p = first ? cnt0 : cnt1;
-    const unsigned want = first ? want0 : want1;
+// two counters in one request: lanes 0..31 read cnt0's shards, lanes 32..63 cnt1's
+__device__ __forceinline__ bool poll_counters2(const unsigned* cnt0, unsigned steps0, unsigned P0, const unsigned* cnt1, unsigned steps1, unsigned P1,
+                                               unsigned* err, unsigned code) {
+    const bool first = (threadIdx.x & 63) < 32;
+    const unsigned sh = threadIdx.x & (NSH - 1);
+    const unsigned* p = (first ? cnt0 : cnt1) + sh * CNT_LINE;
+    const unsigned want = (first ? steps0 : steps1) * shard_share(first ? P0 : P1, sh);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
         const unsigned v = __hip_atomic_load(p, T2_RLX_AGENT);
         if (__all(v >= want)) return true;
         if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_TICKS) {
-            if (first) report_abort(err, code);
+            if ((threadIdx.x & 63) == 0) report_abort(err, code);
             return false;
         }
         __builtin_amdgcn_s_sleep(2);
     }
 }
-// after the payload stores of every wave: drain (every storing wave), workgroup barrier, one lane signals
-__device__ __forceinline__ void publish(unsigned* cnt) {
+// after the payload stores of every wave: drain (every storing wave), workgroup barrier, one lane signals (producer `pidx` of its group)
+__device__ __forceinline__ void publish(unsigned* cnt, unsigned pidx) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, T2_RLX_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt + (pidx & (NSH - 1)) * CNT_LINE, 1u, T2_RLX_AGENT);
 }
 
 }  // namespace chain

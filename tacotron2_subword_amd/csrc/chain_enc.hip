@@ -91,7 +91,7 @@ __global__ __launch_bounds__(NTH) void enc_chain_fwd_kernel(EncChainDesc d) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         if (n > 0) {                                       // h of the previous processed step (zero state before the first)
-            if (wave == 0 && !poll_counter(cnt, (unsigned)n * (unsigned)NUG, d.err, 21u) && lane == 0) *abortw = 1;
+            if (wave == 0 && !poll_counter(cnt, (unsigned)n, (unsigned)NUG, d.err, 21u) && lane == 0) *abortw = 1;
             __syncthreads();
             if (*abortw) return;
             // this lane's 16 consecutive k of row r: two 8-unit chunks of 32 bytes
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(NTH) void enc_chain_fwd_kernel(EncChainDesc d) {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsX,
                 (unsigned)((n & 1) * d.ND + s) * xs_bytes + (unsigned)(((ug * Bp + row0 + (lane >> 1)) * 8 + (lane & 1) * 4) * 4), 0, SC1);
         }
-        publish(cnt);
+        publish(cnt, (unsigned)ug);
         // saved activations and the module's output: plain stores in the slack before the next poll answers
         if (cell && b < B) {
             const long rb = (long)tt * B + b;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(NTH) void enc_chain_bwd_kernel(EncChainBwdDesc d) {
             for (int i = 0; i < 7; ++i) in[i] = pin[i];
             float dh = in[0];
             if (m > 0) {
-                if (wave == 0 && !poll_counter(cntG_wait, (unsigned)m * (unsigned)EGKP, d.err, 22u) && lane == 0) *abortw = 1;
+                if (wave == 0 && !poll_counter(cntG_wait, (unsigned)m, (unsigned)EGKP, d.err, 22u) && lane == 0) *abortw = 1;
                 __syncthreads();
                 if (*abortw) return;
                 const unsigned off = (unsigned)(((m - 1) & 1) * d.ND + s) * pb_bytes + (unsigned)(((pg * Bp + row0 + (tv >> 4)) * EPU + (tv & 15)) * 4);
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NTH) void enc_chain_bwd_kernel(EncChainBwdDesc d) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dgv[g]), rsX, xo + (unsigned)g * (unsigned)((H / 16) * Bp * 64), 0, SC1);
-            publish(cntP);
+            publish(cntP, (unsigned)pg);
             if (pb < B) {                                  // dpre rows (weight-gradient and input-gradient GEMMs)
                 float* gp = d.dpre[s] + ((long)tt * B + pb) * K4 + pu;
                 gp[0] = dgv[0]; gp[H] = dgv[1]; gp[2 * H] = dgv[2]; gp[3 * H] = dgv[3];
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(NTH) void enc_chain_bwd_kernel(EncChainBwdDesc d) {
         }
         // =========================================================================================== G(m)
         if (hasG && m + 1 < T) {                           // (dx of the first forward step feeds nothing)
-            if (wave == 0 && !poll_counter(cntP, (unsigned)(m + 1) * (unsigned)NPG, d.err, 23u) && lane == 0) *abortw = 1;
+            if (wave == 0 && !poll_counter(cntP, (unsigned)(m + 1), (unsigned)NPG, d.err, 23u) && lane == 0) *abortw = 1;
             __syncthreads();
             if (*abortw) return;
             const unsigned base = (unsigned)((m & 1) * d.ND + s) * dg_bytes;
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(NTH) void enc_chain_bwd_kernel(EncChainBwdDesc d) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sum), rsP,
                     (unsigned)((m & 1) * d.ND + s) * pb_bytes + (unsigned)kp * (unsigned)(H * Bp * 4) + (unsigned)(((ch * Bp + row0 + row) * 16 + (c4 & 15)) * 4), 0, SC1);
             }
-            publish(cntG_mine);
+            publish(cntG_mine, (unsigned)kp);
         }
     }
 }

@@ -228,7 +228,8 @@ struct ChainDesc {
 };
 bool chain_plan(ChainDesc& d);                     // fills UT/RT/CS and the residency fields; false = shape not covered
 size_t chain_exchange_bytes(const ChainDesc& d, size_t* x_bytes, size_t* q_bytes);
-constexpr size_t kChainCntBytes = 2 * 4 * 2 * 128; // arrival counters: [NS][row groups <= 4][2] lines of 128 B
+constexpr int kCntShards = 16;                     // every arrival counter is kept as 16 shards, each on a 128-byte line of its own (chain_common.h)
+constexpr size_t kChainCntBytes = (size_t)2 * 4 * 2 * 128 * kCntShards; // arrival counters: [NS][row groups <= 4][2] sharded counters
 int chain_fwd(const ChainDesc& d, hipStream_t s);
 int chain_device_cus();
 // c_api.hip: the current device's sticky status words (page-locked host memory the device writes directly; the pointer is
@@ -271,7 +272,7 @@ struct ChainBwdDesc {
     unsigned char* PBC; unsigned pbc_bytes; float* DQX; float* CARRYX;                       // attention chain: ctx partials, dq partials, boundary carry (LSA: halo rows of dloc + softmax-dot partials)
     int lds_Tc;                                                                              // positions per split of the longest memory (LDS carve)
 };
-constexpr size_t kChainBwdCntBytes = 64 * 128;     // arrival counters, one per 128-byte line
+constexpr size_t kChainBwdCntBytes = (size_t)64 * 128 * kCntShards;     // 64 sharded arrival counters
 bool chain_bwd_plan(ChainBwdDesc& d);
 size_t chain_bwd_exchange_bytes(const ChainBwdDesc& d, size_t* x_bytes, size_t* pb_bytes);
 size_t chain_bwd_lsa_tagged_bytes(const ChainBwdDesc& d);   // LSA: leading part of the carry area (halo rows, tagged softmax-dot slots)
