@@ -80,7 +80,7 @@ def decoder_step_bytes(hp, B, Tin, Tsub, wbytes=4):
                 dec_lstm_bwd_gemm=(4 * Hd * Hd + B * 4 * Hd) * wbytes + 8 * B * Hd * 4)
 
 
-def cpu_baseline(B=64, Tin=100, Tsub=60, T=16, reps=1):
+def cpu_baseline(B=64, Tin=100, Tsub=60, T=128, reps=1):
     """Reported baseline, not the target: the oracle's fp32 training iteration (forward + loss +
     backward + clip + Adam) on the host cores, bounded sample."""
     from oracle import recipe
@@ -287,6 +287,8 @@ def main():
     from tacotron2_subword_amd import train as T
 
     L.set_precision(a.dtype)
+    from tacotron2_subword_amd.utils import cpu_quota, fit_cpu_threads
+    host_threads = fit_cpu_threads()                                    # (load_model does this too; here so that it is reported)
     hp = create_hparams()
     hp.attention = ATTENTION_NAMES[a.attention]
     hp.distributed_run = world > 1
@@ -447,6 +449,7 @@ def main():
                                  "gradients and Adam fp32") if a.dtype == "bf16" else "fp32 everywhere (the parity path)",
                    "recurrent_steps_bf16": bool(a.dtype == "bf16" and B <= 128)},
         "rccl_world_size": torch.distributed.get_world_size() if world > 1 else 1, "dist_backend": backend,
+        "host": {"cpus_visible": os.cpu_count(), "cpu_quota": round(cpu_quota(), 1), "torch_threads": host_threads},
         "loss": round(loss_val, 5),
         "roofline": roof, "kernels": kernels,
     }

@@ -106,7 +106,7 @@ class _Stage:
                 self.buf[name] = b
         v = b[:n].view(*shape)
         if fill is not None:
-            v.fill_(fill)
+            v.numpy().fill(fill)         # numpy on purpose: one thread (see utils.fit_cpu_threads for what torch's pool costs here)
         return v
 
 
@@ -209,21 +209,24 @@ def collate_batch(items, stage=None):
     else:
         pcls = stage.take("pcls", (n, Tin, C), items[0]["phoneme_embedding_cls"].dtype, 0)
         bcls = stage.take("bcls", (n, Tsub, C), items[0]["bert_embedding_cls"].dtype, 0)
+    # numpy views of the stage buffers: plain single-threaded copies (torch's CPU ops would wake its whole intra-op pool)
+    tn, sn, mn, stn, pn, bn = (t.numpy() for t in (text, sub, mel, stop, pcls, bcls))
+    as_np = lambda v: v.numpy() if torch.is_tensor(v) else np.asarray(v)
     for k, it in enumerate(items):
-        text[k, :n_text[k]] = it["text"]
-        sub[k, :n_sub[k]] = it["bert_embedding"]
-        mel[k, :n_mel[k]] = torch.from_numpy(np.ascontiguousarray(it["mel_target"]))
-        stop[k, :n_mel[k]] = torch.from_numpy(np.asarray(it["stop_token"], dtype=np.float64))
+        tn[k, :n_text[k]] = as_np(it["text"])
+        sn[k, :n_sub[k]] = as_np(it["bert_embedding"])
+        mn[k, :n_mel[k]] = it["mel_target"]
+        stn[k, :n_mel[k]] = it["stop_token"]
         if compact:
-            pcls[k] = it["phoneme_embedding_cls"][0]
-            bcls[k] = it["bert_embedding_cls"][0]
+            pn[k] = as_np(it["phoneme_embedding_cls"][0])
+            bn[k] = as_np(it["bert_embedding_cls"][0])
         else:
-            pcls[k, :n_text[k]] = it["phoneme_embedding_cls"]
-            bcls[k, :n_sub[k]] = it["bert_embedding_cls"]
+            pn[k, :n_text[k]] = as_np(it["phoneme_embedding_cls"])
+            bn[k, :n_sub[k]] = as_np(it["bert_embedding_cls"])
     lt = stage.take("length_text", (n,), torch.float64)
     lb = stage.take("length_bert", (n,), torch.float64)
     lm = stage.take("length_mel", (n,), torch.float64)
-    lt.copy_(torch.tensor(n_text, dtype=torch.float64)); lb.copy_(torch.tensor(n_sub, dtype=torch.float64)); lm.copy_(torch.tensor(n_mel, dtype=torch.float64))
+    lt.numpy()[:] = n_text; lb.numpy()[:] = n_sub; lm.numpy()[:] = n_mel
     out = StagedBatch(text=text.numpy(), mel_target=mel.numpy(), stop_token=stop.numpy(), bert_embeddings=sub.numpy(),
                       bert_embeddings_cls=None if compact else bcls, phoneme_embeddings_cls=None if compact else pcls,
                       length_mel=lm.numpy(), length_text=lt.numpy(), length_bert=lb.numpy())
@@ -278,7 +281,9 @@ def batch_to_device(data_of_batch, device="cuda"):
         if device.type != "cuda":
             return t.to(dtype)
         if not t.is_pinned():
-            t = stage.take("_" + name, tuple(t.shape), t.dtype).copy_(t)
+            st = stage.take("_" + name, tuple(t.shape), t.dtype)
+            np.copyto(st.numpy(), t.numpy() if t.is_contiguous() else t.contiguous().numpy())       # (one thread: see collate_batch)
+            t = st
         return t.to(device, non_blocking=True).to(dtype)
 
     character = up(raw("text"), "text", torch.long)

@@ -18,6 +18,7 @@ from .distributed import apply_gradient_allreduce
 from .loss_function import Tacotron2Loss
 from .model import BERT_Tacotron2
 from .optim import FusedAdam
+from .utils import fit_cpu_threads
 
 
 def reduce_tensor(tensor, n_gpus):
@@ -40,7 +41,8 @@ def init_distributed(hparams, n_gpus, rank, group_name=None):
 
 
 def load_model(hparams):
-    """train.py:75-83."""
+    """train.py:75-83.  (Also sizes torch's CPU thread pool to the container's CPU quota: utils.fit_cpu_threads.)"""
+    fit_cpu_threads()
     model = BERT_Tacotron2(hparams).cuda()
     if hparams.fp16_run:
         model.decoder.attention_layer.score_mask_value = float(np.finfo("float16").min)

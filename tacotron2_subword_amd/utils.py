@@ -1,5 +1,40 @@
 """utils.py:10-14,28-33 of the reference, device-agnostic."""
+import os
+
 import torch
+
+
+def cpu_quota():
+    """CPUs this process may actually use: the smaller of its affinity mask and its cgroup CPU quota (cpu.max of cgroup v2,
+    cpu.cfs_quota_us / cpu.cfs_period_us of v1).  A container often SEES every core of the host (os.cpu_count() = 256 on the
+    MI355X boxes) while its quota is 16."""
+    n = float(len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else float(os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, float(q) / float(p))
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, q / p)
+        except (OSError, ValueError):
+            pass
+    return max(1.0, n)
+
+
+def fit_cpu_threads(reserve=2):
+    """Size torch's intra-op thread pool to the CPU quota (never raises it).  Why it matters for the GPU loop: with the default
+    pool (one thread per VISIBLE core) every parallel CPU tensor op wakes hundreds of OpenMP workers that spin for a while
+    afterwards; under a CFS quota they burn the whole period's budget in a few milliseconds and the kernel then freezes the
+    process — the thread that enqueues GPU work included — until the next 100 ms period.  Measured (round 3, scripts/fed_loop.py):
+    a training loop that collates on the host stalled 65-85 ms every third step that way; with the pool sized to the quota
+    it runs at the resident-batch speed.  Returns the thread count in effect."""
+    want = max(1, int(cpu_quota()) - reserve)
+    if torch.get_num_threads() > want:
+        torch.set_num_threads(want)
+    return torch.get_num_threads()
 
 
 def get_mask_from_lengths(lengths, max_len=None):
