@@ -1209,6 +1209,11 @@ int gemm(const GemmDesc& din, hipStream_t s) {
         splitk = (kch + g.kchunks - 1) / g.kchunks;
     }
     d.splitk = splitk;
+    static const int g_log = env_int("T2_GEMM_LOG", 0);      // dev: one line per product (shape, kernel, split, which operands get staged)
+    if (g_log)
+        fprintf(stderr, "t2gemm M=%d N=%d K=%d batch=%d %s%s kernel=%s splitk=%d stageA=%d stageB=%d convA=%d convB=%d beta=%g\n", d.M, d.N, d.K, d.batch,
+                akc ? "A[m][k]" : "A[k][m]", bkc ? " B[n][k]" : " B[k][n]", staged ? (use256 ? "src256" : "src128") : use_bf16 ? "bf16conv" : small ? "f32_64" : "f32_128",
+                splitk, a16 != nullptr, b16 != nullptr, d.conv_a, d.conv_b, (double)d.beta);
     T2_REQUIRE((long)d.batch * splitk <= 65535, "gemm: batch*splitk too large (%d*%d)", d.batch, splitk);
     dim3 grid(tn, tm, d.batch * splitk);
     if (staged) {
