@@ -372,7 +372,7 @@ def decoder_layout(dims: Dims, B: int, T: int, Tin: int, Tsub: int) -> DecoderLa
 
 
 PROF_KINDS = ["att_lstm_fwd", "attention_fwd", "dec_lstm_fwd", "attention_bwd", "att_lstm_bwd_pointwise",
-              "att_lstm_bwd_gemm", "dec_lstm_bwd_pointwise", "dec_lstm_bwd_gemm", "chain_a_fwd", "chain_b_fwd", "chain_b_bwd", "chain_a_bwd"]
+              "att_lstm_bwd_gemm", "dec_lstm_bwd_pointwise", "dec_lstm_bwd_gemm", "chain_a_fwd", "chain_b_fwd", "chain_b_bwd", "chain_a_bwd", "chain_dec"]
 
 
 def prof_enable(max_launches: int) -> None:

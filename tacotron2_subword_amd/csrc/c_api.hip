@@ -37,7 +37,7 @@ using namespace t2;
 // the per-step kernel launches with HIP events on the launch stream.  Off by default.
 // ---------------------------------------------------------------------------------------------
 enum ProfKind { PK_LSTM_ATT_FWD = 0, PK_ATTN_FWD, PK_LSTM_DEC_FWD, PK_ATTN_BWD, PK_LSTM_ATT_BWD_PW, PK_LSTM_ATT_BWD_GEMM,
-                PK_LSTM_DEC_BWD_PW, PK_LSTM_DEC_BWD_GEMM, PK_CHAIN_A_FWD, PK_CHAIN_B_FWD, PK_CHAIN_B_BWD, PK_CHAIN_A_BWD, PK_COUNT };
+                PK_LSTM_DEC_BWD_PW, PK_LSTM_DEC_BWD_GEMM, PK_CHAIN_A_FWD, PK_CHAIN_B_FWD, PK_CHAIN_B_BWD, PK_CHAIN_A_BWD, PK_CHAIN_DEC, PK_COUNT };
 struct Prof {
     bool on = false;
     std::vector<hipEvent_t> ev;
@@ -1485,6 +1485,7 @@ int t2_decoder_infer(const t2_dims* dims_in, const t2_decoder_weights* w, const 
         if (chain) {
             if (t % poll == 0) {                                     // one persistent launch per polling interval
                 cdec.t0 = t; cdec.t1 = std::min(T, t + poll);
+                ProfScope ps(PK_CHAIN_DEC, c.s);
                 T2_TRY(chain_fwd(cdec, c.s));
             }
         } else {

@@ -172,8 +172,10 @@ def decoder_backward(W: L.DecoderWeights, P: dict, dims: L.Dims, dp: DecoderPass
 
 
 def decoder_infer(W: L.DecoderWeights, dims: L.Dims, memory, memory_sub, *, max_steps: int, gate_threshold: float,
-                  prenet_dropout: bool, seed: int = 0, poll_every: int = 16, mem_lengths=None, sub_lengths=None):
+                  prenet_dropout: bool, seed: int = 0, poll_every: int = 0, mem_lengths=None, sub_lengths=None):
     """Autoregressive decode (Decoder.inference, model.py:430-492) for any B.
+    poll_every: decoder steps between two looks at the stop counter (0 = the library's choice: 16 for per-step launches, 32 =
+    one persistent launch per interval when the persistent decode loop runs).
     Returns (DecoderPass sized for max_steps, steps_run, stop_index[B] (int32, -1 = never stopped))."""
     check_chain_status()
     B, Tin, _ = memory.shape

@@ -106,7 +106,18 @@ def test_chain_long_sequence_stays_close_to_fp32(env):
     errs = dict(mel=maxabs(got["mel"], dp.mel), gate=maxabs(got["gate"], dp.gate), align=maxabs(got["align"], dp.align),
                 align_sub=maxabs(got["align_sub"], dp.align_sub))
     print("chain bf16 vs fp32 launches at B=64, T=400:", errs)
-    assert errs["mel"] < 0.08 and errs["gate"] < 0.05 and errs["align"] < 0.02 and errs["align_sub"] < 0.02, errs
+    assert errs["mel"] < 0.012 and errs["gate"] < 0.005 and errs["align"] < 0.004 and errs["align_sub"] < 0.004, errs    # observed 0.0045 / 0.0017 / 0.0012 / 0.0016
+    # ... and against the ORACLE itself (the reference's arithmetic restated on the CPU), two items at full length: the
+    # decoder has no cross-item arithmetic, so an item of the batch equals that item run alone
+    from oracle import tacotron2_oracle as O
+    Pc = recipe.make_weights(hp)
+    idx = [5, 40]
+    with torch.no_grad():
+        mel, gate, al, alb = O.decoder_forward(mem[idx].cpu(), mems[idx].cpu(), mels[idx].cpu(), tl[idx].cpu(), bl[idx].cpu(), Pc, hp)
+    eo = dict(mel=maxabs(got["mel"][idx].cpu().transpose(1, 2), mel), gate=maxabs(got["gate"][idx].cpu(), gate),
+              align=maxabs(got["align"][idx][:, :, :al.shape[2]].cpu(), al), align_sub=maxabs(got["align_sub"][idx][:, :, :alb.shape[2]].cpu(), alb))
+    print("chain bf16 vs the CPU oracle, items 5 and 40, T=400:", eo)
+    assert eo["mel"] < 0.012 and eo["gate"] < 0.005 and eo["align"] < 0.004 and eo["align_sub"] < 0.004, eo
 
 
 @pytest.mark.parametrize("att", [SMA, LSA])
@@ -171,7 +182,7 @@ def test_backward_consumes_chain_activations(env, att):
         n = float(v.norm()) + 1e-12
         worst[k] = float((res[True][k] - v).norm()) / n
     print("relative gradient deviation chain vs launches:", dict(sorted(worst.items(), key=lambda kv: -kv[1])[:6]))
-    assert max(worst.values()) < 0.05, worst
+    assert max(worst.values()) < 0.008, worst                          # observed 0.0038
 
 
 def test_reported_abort_raises_at_every_entry_point(env):
