@@ -312,17 +312,36 @@ def main():
     for _ in range(a.warmup):
         T.train_step(model, criterion, optimizer, x, y, hp, it)
         it += 1
+    arena = getattr(model, "_t2_arena", None)
+    if arena is not None:
+        arena.exposed = []                                              # (events only: nothing synchronises inside the loop)
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = T.train_step(model, criterion, optimizer, x, y, hp, it)
         it += 1
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0                                 # this rank's own loop, before the closing barrier
     sync()
     dt = time.perf_counter() - t0
+    ranks = None
     if world > 1:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
+        # per-rank picture for reading a scaling curve: each rank's own loop time and the part of the gradient reductions
+        # its backward did not hide (time the launch stream spent waiting for them at the end of backward)
+        exposed = sum(e0.elapsed_time(e1) for e0, e1 in arena.exposed) / max(1, len(arena.exposed)) if arena is not None and arena.exposed else 0.0
+        arena.exposed = None
+        mine = torch.tensor([1e3 * dt_local / a.steps, exposed], device="cuda", dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        per = [[round(float(v), 3) for v in t.tolist()] for t in allr]
+        ranks = {"ms_per_step": [p_[0] for p_ in per], "ms_per_step_min": min(p_[0] for p_ in per), "ms_per_step_max": max(p_[0] for p_ in per),
+                 "exposed_allreduce_ms": [p_[1] for p_ in per],
+                 "gradient_bytes": int(arena.flat.numel() * 4) if arena is not None else 0, "buckets": len(arena.buckets) if arena is not None else 0,
+                 "note": "ms_per_step: each rank's own timed loop (before the closing barrier); exposed_allreduce_ms: mean time per step its "
+                         "launch stream waited for the bucketed RCCL reductions at the end of backward (HIP events) — what the overlap did not hide"}
     loss_val = float(loss.item())
     extras = world == 1 and not a.no_extras
 
@@ -450,6 +469,7 @@ def main():
                    "recurrent_steps_bf16": bool(a.dtype == "bf16" and B <= 128)},
         "rccl_world_size": torch.distributed.get_world_size() if world > 1 else 1, "dist_backend": backend,
         "host": {"cpus_visible": os.cpu_count(), "cpu_quota": round(cpu_quota(), 1), "torch_threads": host_threads},
+        "ranks": ranks,
         "loss": round(loss_val, 5),
         "roofline": roof, "kernels": kernels,
     }

@@ -47,6 +47,8 @@ class GradArena:
         self.bucket_of = {p: i for i, b in enumerate(self.buckets) for p in b}
         self.ranges = [(min(self.span[p][0] for p in b), max(self.span[p][1] for p in b)) for b in self.buckets]
         self.live = set()            # parameters that have produced a gradient at least once
+        self.exposed = None          # a list: record (event, event) around the end-of-backward waits (measurement only)
+        self.launch_events = None    # a list: record (bucket, event) when a bucket's reduction is launched (measurement only)
         self.reset()
 
     def view(self, p):
@@ -103,6 +105,9 @@ def apply_gradient_allreduce(module):
             for st in (side, torch.cuda.default_stream()):
                 if st != cur:
                     cur.wait_stream(st)
+        if arena.launch_events is not None and seg.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True); ev.record()
+            arena.launch_events.append((i, hi - lo, ev))
         seg.mul_(1.0 / world)
         arena.handles.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
         arena.launched[i] = True
@@ -114,8 +119,16 @@ def apply_gradient_allreduce(module):
         for i in range(len(arena.buckets)):          # first step / partially-dead buckets
             if not arena.launched[i] and any(p in arena.live for p in arena.buckets[i]):
                 launch(i)
+        # measurement (bench.py --gpus N): how long the launch stream sits in these waits = the part of the reductions that
+        # backward did not hide; a pair of events per step, read after the timed loop
+        rec = arena.exposed is not None and arena.flat.is_cuda
+        if rec:
+            e0 = torch.cuda.Event(enable_timing=True); e0.record()
         for h in arena.handles:
             h.wait()
+        if rec:
+            e1 = torch.cuda.Event(enable_timing=True); e1.record()
+            arena.exposed.append((e0, e1))
         arena.handles = []
 
     def make_hook(p):
