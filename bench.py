@@ -73,8 +73,11 @@ def decoder_step_bytes(hp, B, Tin, Tsub, wbytes=4):
     pw_dec = B * Hd * 16 * 4
     bwd_att = 2 * (4 * Ha * (E + Ha) + B * 4 * Ha) * wbytes + 2 * 8 * B * (E + Ha) * 4
     bwd_dec = (4 * Hd * Hd + B * 4 * Hd) * wbytes + 8 * B * Hd * 4
+    # (the persistent chain's figure leaves out the [Ha/8][B][A] query partials the launch-path kernel writes: they are that
+    #  implementation's own exchange, not bytes the step must move)
+    att_alg = att - 2 * B * (Ha // 8 * A) * 4
     return dict(att_lstm_fwd=att, dec_lstm_fwd=dec, attention_fwd=attn, attention_bwd=2 * attn,
-                chain_a_fwd_per_step=att + attn, chain_b_fwd_per_step=dec,
+                chain_a_fwd_per_step=att_alg + attn, chain_b_fwd_per_step=dec,
                 chain_a_bwd_per_step=2 * attn + pw_att + bwd_att, chain_b_bwd_per_step=pw_dec + bwd_dec,
                 att_lstm_bwd_gemm=2 * (4 * Ha * (E + Ha) + B * 4 * Ha) * wbytes + 2 * 8 * B * (E + Ha) * 4,
                 dec_lstm_bwd_gemm=(4 * Hd * Hd + B * 4 * Hd) * wbytes + 8 * B * Hd * 4)
@@ -416,15 +419,16 @@ def main():
         # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this round (separate --pmc passes, gfx950
         # corrections: profiles/README.md); static, not measured in this run
         traffic, traffic_source = None, None
-        for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        lsa = a.attention == "lsa"
+        for name in (("r03_pmc_hbm_traffic_lsa.json",) if lsa else ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")):
             tpath = os.path.join(ROOT, "profiles", name)
             tkey = {"att_lstm_fwd": "lstm_step_fwd_bf16_grid131072", "dec_lstm_fwd": "lstm_step_fwd_bf16_grid65536",
                     "attention_fwd": "attention_step_fwd_grid131072", "attention_bwd": "attention_step_bwd_grid131072",
                     "att_lstm_bwd_gemm": "lstm_bwd_gemm_bf16_grid393216", "dec_lstm_bwd_gemm": "lstm_bwd_gemm_bf16_grid131072",
                     "att_lstm_bwd_pointwise": "lstm_bwd_pointwise_q_grid65536", "dec_lstm_bwd_pointwise": "lstm_bwd_pointwise_grid65536",
-                    "chain_a_fwd": "chain_fwd_sma", "chain_b_fwd": "chain_fwd_lstm", "chain_a_bwd": "chain_bwd_sma",
-                    "chain_b_bwd": "chain_bwd_lstm"}.get(dom)
-            if not bf or a.attention != "sma" or (B, Tin, Tsub) != (64, 100, 60) or not tkey or not os.path.exists(tpath):
+                    "chain_a_fwd": "chain_fwd_lsa" if lsa else "chain_fwd_sma", "chain_b_fwd": "chain_fwd_lstm",
+                    "chain_a_bwd": "chain_bwd_lsa" if lsa else "chain_bwd_sma", "chain_b_bwd": "chain_bwd_lstm"}.get(dom)
+            if not bf or a.attention not in ("sma", "lsa") or (B, Tin, Tsub) != (64, 100, 60) or not tkey or not os.path.exists(tpath):
                 continue
             ent = json.load(open(tpath)).get(tkey)
             if ent:

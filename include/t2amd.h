@@ -110,7 +110,9 @@ typedef struct t2_dims {
                            the *_sub weights / memory_sub / align_sub are then ignored (0 is read as 2) */
     float score_mask_value, score_mask_value_sub; /* energy written over positions past an item's length: the attention
                            modules' score_mask_value (attention.py:37,79; train.py:77-78 sets the phone stream's to the fp16
-                           minimum for fp16 runs).  0 = the default, -infinity */
+                           minimum for fp16 runs).  Taken verbatim when score_mask_given != 0; otherwise 0 = the default, -infinity */
+    int score_mask_given;  /* 1: the two values above are meant as written (an intentional 0.0 included); 0 (a zero-initialised
+                              struct): a 0.0 there stands for the default */
 } t2_dims;
 
 /* Parameters of Decoder (model.py:128-207), reference state_dict names in comments. */

@@ -9,9 +9,8 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-from oracle import recipe
-from helpers import hp_for, to_dev, SMA, LSA
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _devlib import SMA, LSA, decoder_setup
 from tacotron2_subword_amd import _lib as L, ops
 
 ap = argparse.ArgumentParser()
@@ -20,10 +19,7 @@ ap.add_argument("--T", type=int, default=400)
 ap.add_argument("--att", default="sma")
 a = ap.parse_args()
 L.set_precision("bf16")
-hp = hp_for(SMA if a.att == "sma" else LSA)
-P = to_dev(recipe.make_weights(hp))
-dims = L.dims_from_hparams(hp)
-W = L.decoder_weights(P, dims.attention_kind)
+hp, P, dims, W = decoder_setup(SMA if a.att == "sma" else LSA)
 g = torch.Generator(device="cuda").manual_seed(1)
 mem = torch.randn(a.B, 100, 512, device="cuda", generator=g) * 0.5
 mems = torch.randn(a.B, 60, 512, device="cuda", generator=g) * 0.5

@@ -1,12 +1,10 @@
 """Dev tool (diagnostic build with -DT2_STAMPS only): where one LSTM step launch spends its time."""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-from oracle import recipe
-from helpers import hp_for, to_dev, SMA
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _devlib import SMA, LSA, decoder_setup
 from tacotron2_subword_amd import _lib as L, ops
-hp = hp_for(SMA); P = to_dev(recipe.make_weights(hp)); dims = L.dims_from_hparams(hp)
-W = L.decoder_weights(P, dims.attention_kind)
+hp, P, dims, W = decoder_setup(SMA)
 B, T = 64, 24
 L.set_precision(os.environ.get("T2_PREC", "bf16"))
 mem = torch.randn(B, 100, 512, device="cuda") * .5; mems = torch.randn(B, 60, 512, device="cuda") * .5

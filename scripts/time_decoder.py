@@ -7,9 +7,8 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-from oracle import recipe  # weights recipe only (no oracle arithmetic)
-from helpers import hp_for, to_dev, SMA, LSA
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _devlib import SMA, LSA, decoder_setup
 from tacotron2_subword_amd import _lib as L, ops
 
 ap = argparse.ArgumentParser()
@@ -22,13 +21,11 @@ ap.add_argument("--bwd", type=int, default=1)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--overlap", type=int, default=1)
 ap.add_argument("--prof", type=int, default=1, help="print per-kernel HIP-event averages of one extra pass")
+ap.add_argument("--att", default="sma", help="sma | lsa")
 a = ap.parse_args()
 L.set_precision(a.dtype)
 L.check(L.lib().t2_set_overlap(a.overlap))
-hp = hp_for(SMA)
-P = to_dev(recipe.make_weights(hp))
-dims = L.dims_from_hparams(hp)
-W = L.decoder_weights(P, dims.attention_kind)
+hp, P, dims, W = decoder_setup(SMA if a.att == "sma" else LSA)
 g = torch.Generator(device="cuda").manual_seed(1)
 mem = torch.randn(a.B, a.Tin, 512, device="cuda", generator=g) * 0.5
 mems = torch.randn(a.B, a.Tsub, 512, device="cuda", generator=g) * 0.5

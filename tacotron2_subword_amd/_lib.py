@@ -28,7 +28,7 @@ class Dims(C.Structure):
                 ("dec_rnn_dim", C.c_int), ("att_dim", C.c_int), ("loc_filters", C.c_int), ("loc_kernel", C.c_int),
                 ("attention_kind", C.c_int), ("p_att_dropout", C.c_float), ("p_dec_dropout", C.c_float),
                 ("p_prenet_dropout", C.c_float), ("n_streams", C.c_int),
-                ("score_mask_value", C.c_float), ("score_mask_value_sub", C.c_float)]
+                ("score_mask_value", C.c_float), ("score_mask_value_sub", C.c_float), ("score_mask_given", C.c_int)]
 
 
 class AttentionWeights(C.Structure):

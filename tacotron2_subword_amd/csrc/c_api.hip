@@ -237,7 +237,7 @@ size_t align4(size_t n) { return (n + 3) & ~(size_t)3; }
 // score_mask_value of the stream's attention module; a zero-initialised t2_dims (0.0) means the default, -inf
 float mask_value_of(const t2_dims& d, int stream) {
     const float v = stream ? d.score_mask_value_sub : d.score_mask_value;
-    return v == 0.f ? -INFINITY : v;
+    return (v == 0.f && !d.score_mask_given) ? -INFINITY : v;
 }
 
 // Decode loop, bf16-operand mode: whole-cell weight shadows [W_hh | W_ih[:,P:] | W_ih[:,:P]] (attention LSTMs) and

@@ -229,6 +229,7 @@ class Decoder(nn.Module):
         from outside (train.py:77-78 sets decoder.attention_layer.score_mask_value for fp16 runs)."""
         d = self._dims
         d.score_mask_value = float(self.attention_layer.score_mask_value)
+        d.score_mask_given = 1                                              # (an intentional 0.0 stays 0.0)
         if not self.single:
             d.score_mask_value_sub = float(self.attention_layer_bert.score_mask_value)
         return d

@@ -14,6 +14,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import _lib as L
 from .distributed import apply_gradient_allreduce
 from .loss_function import Tacotron2Loss
 from .model import BERT_Tacotron2
@@ -45,6 +46,11 @@ def load_model(hparams):
     fit_cpu_threads()
     model = BERT_Tacotron2(hparams).cuda()
     if hparams.fp16_run:
+        # train.py:77-78 and :213-216: the reference switches apex amp (O2) on.  Here the flag moves the mask value only: the
+        # arithmetic type of this implementation is chosen with _lib.set_precision ("f32" exact / "bf16" operands), and its
+        # reduced-precision mode is bf16 with fp32 master weights, state and accumulation — no loss scaling, no fp16.
+        print("fp16_run: no apex amp here — arithmetic stays " + L.get_precision() + " (set with tacotron2_subword_amd._lib.set_precision); "
+              "only attention_layer.score_mask_value follows the flag")
         model.decoder.attention_layer.score_mask_value = float(np.finfo("float16").min)
     if hparams.distributed_run:
         model = apply_gradient_allreduce(model)

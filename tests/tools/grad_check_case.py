@@ -1,6 +1,6 @@
 """Diagnostic: per-tensor decoder-backward error (HIP vs fp64 oracle, fp32 oracle vs fp64) for one test configuration."""
 import sys, os
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import torch
 from oracle import recipe, tacotron2_oracle as O
