@@ -1047,7 +1047,9 @@ bool chain_plan(ChainDesc& d) {
     if (d.kind == CHAIN_LSA && (d.F + 1 > 64 || d.F % 16 != 0 || d.A % 32 != 0)) return false;
     const int MT = (d.B + 31) / 32;
     if (d.dec && (MT != 1 || d.NS != 2 || d.kind == CHAIN_LSTM || d.P != 256 || d.Hd != 1024 || d.M + 1 > 96 || d.M % 8 != 0)) return false;
-    if (d.kind == CHAIN_LSTM) { d.UT = 1; d.RT = MT <= 2 ? MT : 2; d.CS = 1; d.NS = 1; }
+    // decoder-LSTM chain: one row tile per item while the items still fit the chip (B <= 64: 128 unit groups x 2 row groups = 256
+    // workgroups; with both tiles in one item half the CUs idled and every step did twice the work per workgroup)
+    if (d.kind == CHAIN_LSTM) { d.UT = 1; d.RT = (d.H / 8) * MT <= 256 ? 1 : 2; d.CS = 1; d.NS = 1; }
     else {
         d.RT = MT <= 2 ? 1 : 2;
         d.UT = (d.NS * (d.H / 8) * ((MT + d.RT - 1) / d.RT) <= 256) ? 1 : 2;
