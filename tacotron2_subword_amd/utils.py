@@ -31,7 +31,9 @@ def fit_cpu_threads(reserve=2):
     process — the thread that enqueues GPU work included — until the next 100 ms period.  Measured (round 3, scripts/fed_loop.py):
     a training loop that collates on the host stalled 65-85 ms every third step that way; with the pool sized to the quota
     it runs at the resident-batch speed.  Returns the thread count in effect."""
-    want = max(1, int(cpu_quota()) - reserve)
+    # several ranks of one job share the container's quota (torchrun exports LOCAL_WORLD_SIZE; bench.py's own launcher WORLD_SIZE)
+    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1))
+    want = max(1, int(cpu_quota() / ranks) - reserve)
     if torch.get_num_threads() > want:
         torch.set_num_threads(want)
     return torch.get_num_threads()

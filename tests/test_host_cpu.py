@@ -110,3 +110,21 @@ def test_checkpoint_roundtrip_and_warm_start(tmp_path):
     m3 = T.warm_start_model(path, m3, ["embedding.weight"])        # hparams.ignore_layers default (hparams.py)
     assert torch.equal(m3.embedding.weight, before)                  # ignored layer keeps its fresh init
     assert torch.equal(m3.decoder.attention_rnn.weight_ih, m.decoder.attention_rnn.weight_ih)
+
+
+def test_cpu_quota_and_thread_pool_sizing(monkeypatch):
+    """utils.cpu_quota / fit_cpu_threads: the pool is sized to what the container may use (never raised), and shared among
+    the ranks of a job (an oversized pool gets the whole process throttled by the CFS quota)."""
+    import torch
+    from tacotron2_subword_amd import utils
+    q = utils.cpu_quota()
+    assert 1.0 <= q <= (os.cpu_count() or 1)
+    before = torch.get_num_threads()
+    try:
+        n = utils.fit_cpu_threads()
+        assert 1 <= n <= before and n <= max(1, int(q))
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+        m = utils.fit_cpu_threads()
+        assert 1 <= m <= max(1, int(q / 8)) or m == 1
+    finally:
+        torch.set_num_threads(before)
