@@ -1,5 +1,7 @@
 """CPU-only checks of the host-side mirror of the reference interface: hparams surface,
 state_dict key/shape contract, mask helper, loss, synthetic batch layout."""
+import os
+
 import pytest
 import torch
 
