@@ -83,7 +83,7 @@ def decoder_step_bytes(hp, B, Tin, Tsub, wbytes=4):
                 dec_lstm_bwd_gemm=(4 * Hd * Hd + B * 4 * Hd) * wbytes + 8 * B * Hd * 4)
 
 
-def cpu_baseline(B=64, Tin=100, Tsub=60, T=128, reps=1):
+def cpu_baseline(B=64, Tin=100, Tsub=60, T=400, reps=1):
     """Reported baseline, not the target: the oracle's fp32 training iteration (forward + loss +
     backward + clip + Adam) on the host cores, bounded sample."""
     from oracle import recipe
