@@ -126,8 +126,19 @@ __global__ __launch_bounds__(NTH) void chain_bwd_lstm_kernel(ChainBwdDesc d) {
                 const unsigned off = (unsigned)(((t + 1) & 1)) * pb_half + (unsigned)((((ug * MT + rt) * 32 + (tv >> 4)) * PU + (tv & 15)) * 4);
                 const unsigned kstride = (unsigned)((H / PU) * MT * 32 * PU * 4);
                 float pv[GKP];
+                const unsigned want = step_tag(ep - 1);               // tag of G(t+1)'s partials (resumed launches: step t1's are drained)
+                const unsigned long long tsp = __builtin_amdgcn_s_memrealtime();
+                for (;;) {
+                    unsigned okw = 1u;
 #pragma unroll
-                for (int z = 0; z < GKP; ++z) pv[z] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsP, off + z * kstride, 0, SC1));
+                    for (int z = 0; z < GKP; ++z) {
+                        const unsigned wv = __builtin_amdgcn_raw_buffer_load_b32(rsP, off + z * kstride, 0, SC1);
+                        pv[z] = __builtin_bit_cast(float, wv);
+                        okw &= ((wv & 1u) == want) ? 1u : 0u;
+                    }
+                    if (ep == 0 || __all(okw != 0u)) break;
+                    if (__builtin_amdgcn_s_memrealtime() - tsp > SPIN_TICKS) { if ((tv & 63) == 0) { report_abort(d.err, 15u); *abortw = 1; } break; }
+                }
                 float acc = 0.f;
 #pragma unroll
                 for (int z = 0; z < GKP; ++z) acc += pv[z];
@@ -159,10 +170,12 @@ __global__ __launch_bounds__(NTH) void chain_bwd_lstm_kernel(ChainBwdDesc d) {
                 bf16x8 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { o[j] = (__bf16)lo[j]; o[4 + j] = (__bf16)hi[j]; }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsX,
+                u32x4 ow = __builtin_bit_cast(u32x4, o);
+                ow.x = (ow.x & ~1u) | step_tag(ep);                   // the unit's tag: lowest mantissa bit of its first element
+                __builtin_amdgcn_raw_buffer_store_b128(ow, rsX,
                     (unsigned)(t & 1) * (unsigned)(KT * MT * 1024) + (unsigned)((((wave * H + u0) / 16) * MT + rt) * 1024 + lane * 16), 0, SC1);
             }
-            publish(cntP_mine, (unsigned)(((u0 % (H / 2)) / PU) * MT + rt));
+            publish_hint(cntP_mine, (unsigned)(((u0 % (H / 2)) / PU) * MT + rt));
             {   // fp32 dg(t) rows for the weight-gradient GEMMs, then next step's operands (cold HBM rows) behind them
                 const int b = rt * 32 + (tv >> 4), u = u0 + (tv & 15);
                 if (b < B) {
@@ -180,11 +193,22 @@ __global__ __launch_bounds__(NTH) void chain_bwd_lstm_kernel(ChainBwdDesc d) {
             f32x16 acc[MT];
             const unsigned xb = (unsigned)(t & 1) * (unsigned)(KT * MT * 1024) + (unsigned)lane * 16u;
             u32x4 af[MT][4];
+            {
+                const unsigned want = step_tag(ep);
+                const unsigned long long tsp = __builtin_amdgcn_s_memrealtime();
+                for (;;) {
+                    unsigned okw = 1u;
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+                    for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    af[m][i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xb + (unsigned)(((kp * KPW / 16 + wave * KSW + min(i, KSW - 1)) * MT + m) * 1024), 0, SC1);
+                        for (int i = 0; i < 4; ++i) {
+                            af[m][i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xb + (unsigned)(((kp * KPW / 16 + wave * KSW + min(i, KSW - 1)) * MT + m) * 1024), 0, SC1);
+                            okw &= ((af[m][i].x & 1u) == want) ? 1u : 0u;
+                        }
+                    if (__all(okw != 0u)) break;
+                    if (__builtin_amdgcn_s_memrealtime() - tsp > SPIN_TICKS) { if (lane == 0) { report_abort(d.err, 16u); *abortw = 1; } break; }
+                }
+            }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -205,10 +229,12 @@ __global__ __launch_bounds__(NTH) void chain_bwd_lstm_kernel(ChainBwdDesc d) {
 #pragma unroll
                 for (int w = 0; w < NWV; ++w) sum += *reinterpret_cast<const f32x4*>(partL + ((w * MT + m) * 32 + row) * PPR + c4);
                 const int ugo = nt * (GNC / PU) + c4 / PU;
+                const unsigned tg = step_tag(ep);                     // every word carries the tag (the consumer reads single words)
+                sum[0] = tag_f32(sum[0], tg); sum[1] = tag_f32(sum[1], tg); sum[2] = tag_f32(sum[2], tg); sum[3] = tag_f32(sum[3], tg);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sum), rsP,
                     (unsigned)(t & 1) * pb_half + (unsigned)((((kp * (H / PU) + ugo) * MT + m) * 32 + row) * PU + (c4 % PU)) * 4u, 0, SC1);
             }
-            publish(cntG_mine, (unsigned)kp);
+            publish_hint(cntG_mine, (unsigned)kp);
         }
     }
     if (hasP && d.t0 > 0 && pb < B) S.dc_state[(long)pb * H + pu] = dc;       // for the launch that continues at t0 - 1
@@ -1148,6 +1174,12 @@ int chain_bwd(const ChainBwdDesc& d, hipStream_t s) {
         return 0;
     }
     T2_REQUIRE(d.kind == CHAIN_LSTM, "chain_bwd: kind %d not covered", d.kind);
+    T2_REQUIRE(d.t1 == d.T, "chain_bwd: the decoder-LSTM chain runs its whole step range in one launch (tagged hand-offs count steps from the launch)");
+    {   // tagged hand-offs: fragments and partials start out with tag 0 (= invalid for the first two steps)
+        size_t xb = 0, pb = 0;
+        chain_bwd_exchange_bytes(d, &xb, &pb);
+        T2_CHECK_HIP(hipMemsetAsync(d.X, 0, xb + pb, s));
+    }
     const size_t smem = (size_t)(4 + NWV * MT * 32 * PPR) * sizeof(float);
     const int grid = (d.H / GNC) * GKP;
     if (MT == 1) {

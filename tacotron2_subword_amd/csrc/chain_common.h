@@ -84,6 +84,20 @@ __device__ __forceinline__ void publish(unsigned* cnt, unsigned pidx) {
     if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt + (pidx & (NSH - 1)) * CNT_LINE, 1u, T2_RLX_AGENT);
 }
 
+// ---- tagged, drain-free hand-off (round 3, chain_bwd_lstm_kernel) ---------------------------------------------------------
+// The producer's s_waitcnt vmcnt(0) in front of its arrival add costs the consumers the store round trip of the slowest
+// producer.  Here the add goes out right behind the stores (a HINT), and the payload validates itself: bit 0 of every stored
+// 32-bit word (fp32 payloads) or of the first word of every 16-byte unit (bf16 fragments) is a tag that flips each time a
+// slot is rewritten (slots alternate by step parity, so the tag is bit 1 of the step count, inverted: buffers are zeroed per
+// launch and the first valid tag is 1).  A consumer whose loads still show the old tag loads again (bounded).  16-byte sc1
+// stores have been observed untorn on gfx950 (MI355X_MICROARCH.md, Valid forms; scripts/persist_probe: 0 torn units).
+__device__ __forceinline__ unsigned step_tag(unsigned steps_done) { return ((steps_done >> 1) & 1u) ^ 1u; }
+__device__ __forceinline__ void publish_hint(unsigned* cnt, unsigned pidx) {
+    __syncthreads();                                         // every wave has ISSUED its payload stores
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt + (pidx & (NSH - 1)) * CNT_LINE, 1u, T2_RLX_AGENT);
+}
+__device__ __forceinline__ float tag_f32(float v, unsigned tag) { return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, v) & ~1u) | tag); }
+
 }  // namespace chain
 
 // Host side, before every persistent launch: dynamic-LDS attribute (cached per device and kernel), the sticky status
