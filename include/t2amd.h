@@ -45,7 +45,7 @@ const char* t2_last_error(void);
 /* ABI version: bumped whenever a struct below grows or an argument changes meaning.  2 (round 3): t2_dims carries
  * score_mask_value[_sub], the layouts carry chain / chain_floats, norm_out of t2_adam_* is 4 floats.  A caller compiled
  * against another version passes structs of another size: check t2_version() == T2_ABI_VERSION before anything else. */
-#define T2_ABI_VERSION 2
+#define T2_ABI_VERSION 3
 int t2_version(void);
 /* Sticky status of the persistent kernels of the current device (the reference's nearest analogue: train.py:335-340,
  * which at least notices a NaN gradient norm).  A chain whose hand-off timed out writes a non-zero code into a word in
@@ -168,6 +168,9 @@ typedef struct t2_decoder_layout {
     size_t chain; size_t chain_floats;   /* exchange buffers of the persistent chain kernels (t2_set_chain): word 0 = status of
                                           * the attention chain, word 1 = status of the decoder-LSTM chain (0 = OK), then arrival
                                           * counters, fragment-ordered h / ctx buffers, query partials */
+    size_t usave, usaves;             /* LSA: tanh(q + pm + location term) of every step [T,B,A,Tin4], [T,B,A,Tsub4] (Tin4 = Tin rounded up to 4) and ... */
+    size_t locsave, locsaves;         /* ... the location features [T,B,Tin,F], [T,B,Tsub,F]: written by the persistent forward
+                                       * chain for the persistent backward chain (size 0 for the other attention kinds) */
 } t2_decoder_layout;
 
 int t2_decoder_layout_query(const t2_dims* dims, int B, int T, int Tin, int Tsub, t2_decoder_layout* out);

@@ -50,7 +50,7 @@ class DecoderWeights(C.Structure):
 _LAYOUT_FIELDS = ["total_floats", "x", "p1", "p2", "p1s", "p2s", "pm", "pms", "prea", "preas", "ga", "gas",
                   "cna", "cnas", "ca", "cas", "din", "psel", "psels", "wcum", "wcums", "pred", "gd", "cnd", "cd",
                   "dout", "qs", "qss", "qpart", "w1t", "w16a", "w16as", "w16d", "wt16a", "wt16as", "wt16d", "din16", "dh16",
-                  "gemm_ws", "gemm_ws_floats", "chain", "chain_floats"]
+                  "gemm_ws", "gemm_ws_floats", "chain", "chain_floats", "usave", "usaves", "locsave", "locsaves"]
 
 
 class DecoderLayout(C.Structure):
@@ -150,7 +150,7 @@ class GemmArgs(C.Structure):
 
 
 # every symbol include/t2amd.h declares (tests/test_abi.py checks the library exports them all)
-ABI_VERSION = 2      # include/t2amd.h T2_ABI_VERSION: struct sizes below match that header and nothing else
+ABI_VERSION = 3      # include/t2amd.h T2_ABI_VERSION: struct sizes below match that header and nothing else
 
 EXPORTS = ["t2_last_error", "t2_version", "t2_chain_status", "t2_chain_status_clear", "t2_debug_report_abort", "t2_debug_occupy", "t2_chain_claimed", "t2_set_precision", "t2_get_precision", "t2_set_overlap", "t2_set_chain", "t2_get_chain", "t2_set_chain_bwd", "t2_set_gemm_staging", "t2_side_join", "t2_decoder_layout_query", "t2_decoder_forward", "t2_decoder_infer",
            "t2_decoder_bwd_layout_query", "t2_decoder_backward", "t2_prof_enable", "t2_prof_collect", "t2_adam_chunks", "t2_adam_step", "t2_adam_norm",

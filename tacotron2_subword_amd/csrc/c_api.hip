@@ -28,6 +28,7 @@ void t2_set_error(const char* fmt, ...) {
 
 #include <algorithm>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 using namespace t2;
@@ -317,6 +318,11 @@ void layout_of(const t2_dims& d, const Sizes& z, t2_decoder_layout* L) {
     // exchange buffers of the persistent chain kernels (chain.hip), see chain_bufs()
     L->chain_floats = chain_region_bytes(z) / sizeof(float);
     L->chain = take(L->chain_floats);
+    // LSA: tanh tile and location features of every step, written by the forward chain for the backward chain (which then
+    // repeats neither the location conv nor the tile: 1.3 GB + 0.33 GB per stream at B = 64, T = 400 — HBM is what this part has)
+    const bool lsa = d.attention_kind == T2_ATTN_LSA;
+    L->usave = take(lsa ? BT * align4(z.Tin) * z.A : 0); L->usaves = take(lsa && z.NS > 1 ? BT * align4(z.Tsub) * z.A : 0);   // [T][B][A][Tin rounded up to 4]
+    L->locsave = take(lsa ? BT * z.Tin * d.loc_filters : 0); L->locsaves = take(lsa && z.NS > 1 ? BT * z.Tsub * d.loc_filters : 0);
     L->total_floats = off;
 }
 
@@ -558,6 +564,7 @@ bool chain_a_desc(const Dec& c, ChainDesc* out) {
         st.align = s ? c.align_sub : c.align; st.psel = c.P(s ? L.psels : L.psel); st.wcum = c.P(s ? L.wcums : L.wcum);
         st.qs = c.P(s ? L.qss : L.qs);
         st.v = aw.v; st.loc_conv = aw.loc_conv; st.loc_dense = aw.loc_dense;
+        if (d.kind == CHAIN_LSA) { st.usave = c.P(s ? L.usaves : L.usave); st.locsave = c.P(s ? L.locsaves : L.locsave); }
         st.site_h = s ? T2_SITE_ATT_H_SUB : T2_SITE_ATT_H; st.site_c = s ? T2_SITE_ATT_C_SUB : T2_SITE_ATT_C;
         st.site_noise = s ? T2_SITE_NOISE_SUB : T2_SITE_NOISE;
         st.mask_value = mask_value_of(c.d, s);
@@ -806,11 +813,28 @@ bool chain_b_bwd_desc(const Bwd& c, ChainBwdDesc* out) {
     return true;
 }
 
+// The LSA backward chain reads the tanh tile and the location features the forward CHAIN saved (layout.usave / locsave); a
+// workspace filled by the per-step launch path does not hold them.  Which workspaces do is kept here, per base pointer
+// (every forward pass notes its own; host-side only, no device round trip).
+std::mutex g_saved_mu;
+std::unordered_map<const void*, bool> g_saved_tiles;
+void saved_tiles_note(const void* ws, bool saved) {
+    std::lock_guard<std::mutex> lk(g_saved_mu);
+    if (g_saved_tiles.size() > 4096) g_saved_tiles.clear();
+    g_saved_tiles[ws] = saved;
+}
+bool saved_tiles_have(const void* ws) {
+    std::lock_guard<std::mutex> lk(g_saved_mu);
+    auto it = g_saved_tiles.find(ws);
+    return it != g_saved_tiles.end() && it->second;
+}
+
 // Persistent BPTT of the attention chain (both attention LSTMs + SMA attention); false = not covered
 bool chain_a_bwd_desc(const Bwd& c, ChainBwdDesc* out) {
     const Sizes& z = c.z;
     const bool lsa = c.d.attention_kind == T2_ATTN_LSA;
     if (!c.use16 || !(lsa || (c.d.attention_kind == T2_ATTN_SMA && attn_bwd_nsplit(c.d, z) == 2))) return false;
+    if (lsa && !saved_tiles_have(c.a.ws)) return false;              // forward ran on the launch path: its workspace has no tanh tile
     ChainBwdDesc d{};
     d.NS = z.NS; d.B = z.B; d.T = z.T; d.H = z.Ha; d.E = z.E; d.A = z.A; d.kind = lsa ? CHAIN_LSA : CHAIN_SMA;
     d.F = c.d.loc_filters; d.Kc = c.d.loc_kernel;
@@ -836,6 +860,7 @@ bool chain_a_bwd_desc(const Bwd& c, ChainBwdDesc* out) {
         st.dv_acc = c.S(s ? c.BL.dvs : c.BL.dv); st.dpm_acc = c.S(s ? c.BL.dpms : c.BL.dpm);
         if (lsa) {
             st.wcum = c.W(s ? c.L.wcums : c.L.wcum); st.loc_conv = aw.loc_conv; st.loc_dense = aw.loc_dense;
+            st.usave = c.W(s ? c.L.usaves : c.L.usave); st.locsave = c.W(s ? c.L.locsaves : c.L.locsave);
             st.dconv_acc = c.S(s ? c.BL.dlconvs : c.BL.dlconv); st.ddense_acc = c.S(s ? c.BL.dldenses : c.BL.dldense);
         }
     }
@@ -1101,6 +1126,7 @@ int t2_decoder_forward(const t2_dims* dims_in, const t2_decoder_weights* w, cons
     // run back to back on the caller's stream: A over all steps, one input GEMM, B over all steps.
     ChainDesc ca{}, cb{};
     const bool chain_a = g_chain && chain_a_desc(c, &ca), chain_b = g_chain && chain_b_desc(c, &cb);
+    saved_tiles_note(a->ws, chain_a && ca.kind == CHAIN_LSA);
     {   // status words always (0 = OK / not used); counters and the zero state of step -1 when a chain runs
         const ChainBufs bufs = chain_bufs(z, L, a->ws);
         T2_CHECK_HIP(hipMemsetAsync(bufs.err, 0, (chain_a || chain_b) ? 256 + 2 * kChainCntBytes + bufs.xa_bytes + bufs.xb_bytes + kChainXmBytes : 256, c.s));

@@ -410,6 +410,18 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             d.dout[rb * d.WO + AS.ctx2off + c0 + c] = x;
             d.din16[rb * d.WD + AS.coff + c0 + c] = (__bf16)x;
         }
+        // LSA: the step's location features (still in locL), for the backward chain — which then repeats neither the location
+        // conv nor the tanh tile (chain_bwd.hip); the item's parts take the rows in turn
+        if (KIND == CHAIN_LSA && AS.locsave) {
+            const int F = d.F, F1 = F + 1;
+            float* ls = AS.locsave + rb * Tin * F;
+            for (int i = tid; i < Tin * (F / 4); i += NTH) {
+                const int j = i / (F / 4), f4 = (i % (F / 4)) * 4;
+                if (j % d.CS != part) continue;
+                const float* lr = locL + j * F1 + f4;
+                *reinterpret_cast<f32x4*>(ls + j * F + f4) = f32x4{lr[0], lr[1], lr[2], lr[3]};
+            }
+        }
 #endif
     };
 #ifdef T2_STAMPS
@@ -655,7 +667,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 // with the POSITIONS on the lanes, so each lane sums its 16 channel rows in registers; the partials of the
                 // A/32 channel tiles meet in LDS ([A/32][Tp]).  pm rows are LDS-resident with an odd pitch (conflict-free
                 // position-major reads).
-                const int F1 = d.F + 1, Ke = (d.F + 1) & ~1, njt = (Tin + 31) / 32, nat = A / 32;
+                const int F1 = d.F + 1, Ke = (d.F + 1) & ~1, njt = (Tin + 31) / 32, nat = A / 32, TinP = (Tin + 3) & ~3;
                 const int r_ = lane & 31, h_ = lane >> 5;
                 constexpr float K2 = 2.0f * 1.44269504088896341f;
                 for (int tile = wave; tile < njt * nat; tile += NWV) {
@@ -679,11 +691,20 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                     const float* qr = qL + at * 32 + 4 * h_;
                     const float* vr = vL + at * 32 + 4 * h_;
                     float sum = 0.f;
+                    // u = tanh(x) = 1 - 2 / (exp(2x) + 1): the tiles of the [Tin x A] tile are saved by the item's parts in turn, for
+                    // the backward chain.
+                    // Layout [T][B][A][TinP] (channel-major, positions contiguous): a store instruction then covers two channel
+                    // rows x 32 consecutive positions = two 128-byte lines (position-major rows put every lane on a line of its own:
+                    // measured +1.7 us per step).  Every wave stores one of its tiles.
+                    float* up = (!DEC && AS.usave && (tile / NWV + wave) % d.CS == part && jt * 32 + r_ < Tin)
+                                    ? AS.usave + (((long)t * B + ab_) * A + at * 32 + 4 * h_) * TinP + j : nullptr;
 #pragma unroll
                     for (int e2 = 0; e2 < 16; ++e2) {
                         const int ao = (e2 & 3) + 8 * (e2 >> 2);
                         const float x = qr[ao] + pr[ao] + acc[e2];
-                        sum += vr[ao] * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(K2 * x) + 1.0f);
+                        const float sg = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(K2 * x) + 1.0f);
+                        sum += vr[ao] * sg;
+                        if (up) up[ao * TinP] = 1.0f - 2.0f * sg;
                     }
                     sum += __shfl_xor(sum, 32, 64);
                     if (h_ == 0 && jt * 32 + r_ < Tin) paL[at * Tp + jt * 32 + r_] = sum;

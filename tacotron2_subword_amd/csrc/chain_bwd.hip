@@ -394,7 +394,6 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
     float* ccL = smem + M.cc; float* convwL = smem + M.convw; float* dlocL = smem + M.dloc; float* wpadL = smem + M.wpad;
     float* utL = smem + M.scratch + M.ut; float* locL = smem + M.scratch + M.loc; float* lredL = smem + M.scratch + M.red;
     (void)F1; (void)TwP; (void)UP; (void)WN; (void)CP; (void)wL; (void)ccL; (void)convwL; (void)dlocL; (void)wpadL; (void)utL; (void)locL; (void)lredL;
-    const int ljt = wave >> 2, lat = wave & 3;                       // LSA: this wave's (position tile, channel tile) of the [len x A] tile
     // one bf16 MFMA operand (8 consecutive K values of this lane) gathered from fp32 LDS values
     auto pack8 = [&](auto f) {
         bf16x8 o;
@@ -431,7 +430,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
     float ain[6];                                                   // per thread: q_a | p_j (LSA: w_j), a_prev_j (LSA: [w; cum](t-1) with halos), dalign_j | two direct dctx sources
     auto load_ain = [&](int t, int tid) {
         const long rb = (long)t * B + ab_;
-        ain[0] = tid < A ? AS.qs[rb * A + tid] : 0.f;
+        ain[0] = (KIND != CHAIN_LSA && tid < A) ? AS.qs[rb * A + tid] : 0.f;      // (LSA reads the saved tanh tile instead)
         const int j = jb + tid;
         const bool in = tid < ng;
         if constexpr (KIND == CHAIN_LSA) {
@@ -629,38 +628,35 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                     if ((split == 0 && je < Tin) || (split == 1 && jb > 0)) { dst[0] = h4[0]; dst[1] = h4[1]; dst[2] = h4[2]; dst[3] = h4[3]; }
                 }
             }
-            if (tid < A) qL[tid] = in[0];
+            // the tanh tile u = tanh(q + pm + location term) and the location features of step t, own positions: saved by the
+            // forward chain (chain.hip), requested here — behind the halo rows, vector loads complete in order — and in
+            // flight underneath the carried-gradient products (cold HBM lines: ~2 us)
+            // Tile layout in memory: [A][TinP], positions contiguous (what the forward's MFMA tiles store coalesced).  A wave
+            // request covers 16 channel rows x 4 consecutive 16-byte pieces; the LDS tile is [position][A + 4], so the four
+            // transposing writes of a lane land 2-way conflicted at worst.
+            f32x4 ureg[4], lreg;
+            const int TinP = (Tin + 3) & ~3, nj4 = (len + 3) >> 2;
+            {
+                const float* us = AS.usave + ((long)t * B + ab_) * A * TinP + jb;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int w = wave + NWV * k, a = (w & 7) * 16 + (lane & 15), j4 = min((w >> 3) * 4 + (lane >> 4), nj4 - 1);
+                    ureg[k] = *reinterpret_cast<const f32x4*>(us + (long)a * TinP + 4 * j4);
+                }
+                const int i = min(tid, len * (F / 4) - 1);
+                lreg = *reinterpret_cast<const f32x4*>(AS.locsave + (((long)t * B + ab_) * Tin + jb + i / (F / 4)) * F + (i % (F / 4)) * 4);
+            }
             if (tid < len) wL[tid] = in[1];
             if (tid < 2 * WN) { const int c = tid / WN; wnew[c * TwP + (tid - c * WN)] = in[2]; }
             __syncthreads();
             T2_BSTAMP(11);
-            // work units of this stage over the 8 waves: 0,1 the location features of the two position tiles (32 chained fp32
-            // MFMAs: the long pole); 2..7 one Q tile each (two bf16 MFMAs), 2,3 then a d(Wc) column tile (four)
-            if (wave < njt) {
-                // loc[j][f] = sum_{c,k} Wc[f][c][k] wcat[c][j + k - pad]: Toeplitz product on the matrix cores (exact fp32 fma chains)
-                const float* xr = wnew + min(wave * 32 + r, len - 1);
-                const float* wr = convwL + min(r, F - 1) * CP;
-                f32x16 acc;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-                // K = CP (2 Kc padded with zero weights: the matching [w; cum] reads stay inside the padded row)
-                acc = mfma_chain(CP / 2, [&](int i) { const int ck = 2 * i + hk, c = ck >= Kc ? 1 : 0; return xr[c * TwP + ck - c * Kc]; },
-                                 [&](int i) { return wr[2 * i + hk]; }, acc);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int jl = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk;
-                    if (jl < len && r < F) locL[jl * F1 + r] = acc[e];
-                }
-                if (hk == 0 && wave * 32 + r < len) locL[(wave * 32 + r) * F1 + F] = 0.f;      // pad column (K of the products below is even)
-            }
-            if (ep > 0 && wave >= 2) {
+            if (ep > 0) {
                 // gradient on [w_t; cum_t] through the location conv of step t+1, dwcat[c][i] = sum_{f,k} Wc[f][c][k] dloc[i - k + pad][f],
                 // in two steps: Q[p][(c,k)] = sum_f dloc[p][f] Wc[f][(c,k)] on the matrix cores (rows p = own positions and both
-                // halos: 3 x 2 tiles, one per wave 2..7), then dwcat[c][i] = the anti-diagonal sum_k Q[i + 2 pad - k][(c,k)].
-                // bf16 operands, as every gradient product of this mode (the fp32 pipe is what bounds this phase: 64 cycles per
-                // K = 2 against 32 per K = 16).
-                const int NP = len + 2 * pad, pt = (wave - 2) >> 1, nq = (wave - 2) & 1;
-                if (pt * 32 < NP && nq * 32 < 2 * Kc) {
+                // halos: 3 x 2 tiles, one per wave 0,1,4..7), then dwcat[c][i] = the anti-diagonal sum_k Q[i + 2 pad - k][(c,k)].
+                // bf16 operands, as every gradient product of this mode.  Waves 2,3: a d(Wc) column tile each.
+                const int NP = len + 2 * pad, qi = wave < 2 ? wave : wave - 2, pt = qi >> 1, nq = qi & 1;
+                if ((wave < 2 || wave >= 4) && pt * 32 < NP && nq * 32 < 2 * Kc) {
                     const float* ar = dlocL + min(pt * 32 + r, NP - 1) * F1 + 8 * hk;
                     const float* br = convwL + 8 * hk * CP + min(nq * 32 + r, 2 * Kc - 1);
                     f32x16 acc;
@@ -679,7 +675,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                         }
                     }
                 }
-                if (wave < 4 && (wave - 2) * 32 < 2 * Kc) {
+                if ((wave == 2 || wave == 3) && (wave - 2) * 32 < 2 * Kc) {
                     // d(Wc)[f][(c,k)] += sum_j dloc(t+1)[j][f] wcat(t+1)[c][j + k - pad]   (rows f, columns (c,k), K = own positions)
                     const int n = min((wave - 2) * 32 + r, 2 * Kc - 1), c = n / Kc, k = n - c * Kc;
                     const float* ar = dlocL + pad * F1 + min(r, F);
@@ -694,19 +690,6 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
             }
             __syncthreads();
             T2_BSTAMP(12);
-            // operands of the tanh tile further down (L2-resident rows of Wd and of the processed memory): requested here,
-            // in flight underneath the diagonal sums (requested in front of the products above they cost more than they hide: measured)
-            float wdf[16], pv[16];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {                                // K index (i, hk) of the pa product <-> feature f = 16 hk + i: 64 contiguous bytes per lane
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(AS.loc_dense + (long)(lat * 32 + r) * F + 16 * hk + 4 * i);
-                wdf[4 * i] = w4[0]; wdf[4 * i + 1] = w4[1]; wdf[4 * i + 2] = w4[2]; wdf[4 * i + 3] = w4[3];
-            }
-            {
-                const float* pmr = AS.pm + ((long)ab_ * Tin + jb) * A + lat * 32 + r;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) pv[e] = pmr[(long)min(min(ljt, njt - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk, len - 1) * A];
-            }
             if (ep > 0 && tid < 2 * len) {
                 const int c = tid / len, i = tid - c * len;
                 const float* qp = utL + (i + 2 * pad) * 65 + c * Kc;
@@ -715,27 +698,19 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                 if (c == 0) carryL[i] = sum; else ccL[i] += sum;
             }
             __syncthreads();
-            // pa = loc . Wd^T for this wave's [32 positions x 32 channels] tile, then u = tanh(q + pm + pa) into the tile
-            if (ljt < njt) {
-                const float* lr = locL + min(ljt * 32 + r, len - 1) * F1 + 16 * hk;
-                f32x16 acc;
+            // the saved tile and features into LDS (the tile's room held Q until here)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-                {
-                    float lv[16];
+            for (int k = 0; k < 4; ++k) {
+                const int w = wave + NWV * k, a = (w & 7) * 16 + (lane & 15), j4 = (w >> 3) * 4 + (lane >> 4);
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) lv[i] = lr[i];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lv[i], wdf[i], acc, 0, 0, 0);
-                }
-                const int a = lat * 32 + r;
-                const float qa = qL[a];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int jl = ljt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk;
-                    if (jl < len) utL[jl * UP + a] = fast_tanh(qa + pv[e] + acc[e]);
-                }
+                for (int c = 0; c < 4; ++c)
+                    if (4 * j4 + c < len) utL[(4 * j4 + c) * UP + a] = ureg[k][c];
             }
+            if (tid < len * (F / 4)) {
+                float* lw = locL + (tid / (F / 4)) * F1 + (tid % (F / 4)) * 4;
+                lw[0] = lreg[0]; lw[1] = lreg[1]; lw[2] = lreg[2]; lw[3] = lreg[3];
+            }
+            if (tid < len) locL[tid * F1 + F] = 0.f;                      // pad column (read by lanes r >= F of the d(Wd) product)
             // ------------------------------------------------------------------------------------------------------------
             T2_BSTAMP(13);
             if (ep > 0) {
@@ -1119,6 +1094,7 @@ bool chain_bwd_plan(ChainBwdDesc& d) {
         if (Tin < 16) return false;                                  // (two position splits per item, as the launch path at these sizes)
         // LSA: both splits hold at least the `pad` rows they hand to each other; one [positions x A] tile row pair per wave
         if (lsa && (Tin - chunk < pad || chunk < pad || chunk > 64)) return false;
+        if (lsa && (!d.st[s].usave || !d.st[s].locsave)) return false;   // the forward chain's tanh tile / location features
         tc = std::max(tc, chunk);
     }
     d.lds_Tc = tc;

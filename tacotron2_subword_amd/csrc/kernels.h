@@ -200,6 +200,7 @@ struct ChainStream {
     const float* pm; const float* memory; const int* lengths; int Tin;   // [B,Tin,A], [B,Tin,E], [B] (nullable)
     float* align; float* psel; float* wcum; float* qs;                   // [B,T,Tin] x3, [T,B,A]
     const float* v; const float* loc_conv; const float* loc_dense;
+    float* usave; float* locsave;         // LSA, teacher-forced: tanh tile [T][B][A][Tin rounded up to 4] and location features [T][B][Tin][F] for the backward chain (nullable)
     uint32_t site_h, site_c, site_noise;
     float mask_value;                     // energy of positions past the item's length
 };
@@ -260,6 +261,7 @@ struct ChainBwdStream {
     float* dpm_acc;                       // [B][Tin][A]
     // CHAIN_LSA (attention.py:26-85): saved cumulative weights, location-layer weights, per-(split, item) accumulators
     const float* wcum;                    // [B,T,Tin]
+    const float* usave; const float* locsave;        // saved by the forward chain: tanh tile [T][B][A][Tin rounded up to 4], location features [T][B][Tin][F]
     const float* loc_conv; const float* loc_dense;   // [F][2][Kc], [A][F]
     float* dconv_acc; float* ddense_acc;  // [2][B][F][2Kc], [2][B][A][F]
     const __bf16* wdt16;                  // [F][A] bf16 transpose of loc_dense (made by the caller in the exchange area)
