@@ -73,7 +73,7 @@ __host__ __device__ inline Geo geo_of(const ChainDesc& d, int UT, int RT) {
 }
 
 // LDS carve (floats).  Persistent part first, then a scratch area shared by the two phases.
-struct Lds { int ab, v, ap, cum, q, e, an, cs, pm, mem, convw, dense, loc, wpad, pa, scratch, total; };
+struct Lds { int ab, v, ap, cum, q, e, an, cs, pm, mem, convw, dense, loc, wpad, pa, lsp, scratch, total; };
 __host__ __device__ inline Lds lds_of(const ChainDesc& d, int UT, int RT, int Tin, int Jp, int Jm) {
     Lds m; int o = 0;
     auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
@@ -87,19 +87,22 @@ __host__ __device__ inline Lds lds_of(const ChainDesc& d, int UT, int RT, int Ti
         if (d.dec && o - m.pm < 16384) take(16384 - (o - m.pm));
     } else { m.v = m.ap = m.cum = m.q = m.e = m.an = m.cs = m.pm = m.mem = o; }
     m.convw = m.dense = o;
-    if (d.kind == CHAIN_LSA) { m.convw = take(d.F * ((2 * d.Kc + 15) & ~15)); m.dense = take(d.A * (d.F + 1)); }   // location layer weights, resident (conv taps zero-padded to a multiple of 16)
+    // location layer weights, resident, each as a bf16 hi/lo pair: conv taps [2][F][2 KP + 8] (KP = Kc rounded up to 8, zero taps
+    // behind Kc), dense layer [2][A][F + 8]
+    if (d.kind == CHAIN_LSA) { m.convw = take(d.F * (2 * ((d.Kc + 7) & ~7) + 8)); m.dense = take(d.A * (d.F + 8)); }
     const int lpart = NWV * 32 * PPR, lhs = RT * 32 * (UT * 8 + 4), lq = d.kind == CHAIN_LSTM ? 0 : RT * 32 * (d.A + 4);
     const int lphase = (lpart > lq ? lpart : lq) + lhs;
     int aphase = d.kind == CHAIN_LSTM ? 0 : 16 * d.A + NWV * EC;
-    m.loc = m.wpad = m.pa = 0;
+    m.loc = m.wpad = m.pa = m.lsp = 0;
     if (d.kind == CHAIN_LSA) {                               // per-step location features behind the reduction buffers
         const int TwP = (Tin + d.Kc - 1 + 8 + 3) & ~3;
         m.loc = aphase; aphase += (Tin * (d.F + 1) + 3) & ~3;
         m.wpad = aphase; aphase += 2 * TwP;
         m.pa = aphase; aphase += (d.A / 32) * ((Tin + 3) & ~3);   // energy partials of the channel tiles [A/32][Tp]
+        m.lsp = aphase; aphase += (Tin * (d.F + 8) + 3) & ~3;     // the features again as a bf16 hi/lo pair [2][Tin][F + 8]
     }
     m.scratch = take(lphase > aphase ? lphase : aphase);
-    m.loc += m.scratch; m.wpad += m.scratch; m.pa += m.scratch;
+    m.loc += m.scratch; m.wpad += m.scratch; m.pa += m.scratch; m.lsp += m.scratch;
     m.total = o;
     return m;
 }
@@ -147,9 +150,10 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
     float* hsL = smem + M.scratch + (NWV * 32 * PPR > lq ? NWV * 32 * PPR : lq);   // [RT*32][HSP]
     float* redL = smem + M.scratch;                                    // [16][A]             (A phase)
     float* credL = smem + M.scratch + 16 * A;                          // [NWV][EC]
-    float* convwL = smem + M.convw; float* denseL = smem + M.dense;    // LSA: [F][2][Kc], [A][F+1]
+    __bf16* convwL = reinterpret_cast<__bf16*>(smem + M.convw); __bf16* denseL = reinterpret_cast<__bf16*>(smem + M.dense);    // LSA: bf16 [hi|lo][F][2KP+8], [hi|lo][A][F+8]
+    __bf16* lspL = reinterpret_cast<__bf16*>(smem + M.lsp);                                            // LSA: bf16 [hi|lo][Tin][F+8]
     float* locL = smem + M.loc; float* wpadL = smem + M.wpad; float* paL = smem + M.pa;   // LSA: [Tin][F+1], [2][TwP], [A/32][Tp]
-    (void)convwL; (void)denseL; (void)locL; (void)wpadL; (void)paL;
+    (void)convwL; (void)denseL; (void)locL; (void)wpadL; (void)paL; (void)lspL;
     (void)cumL; (void)qsL; (void)redL; (void)credL; (void)csL; (void)eL; (void)anL; (void)qL; (void)vL; (void)pmL; (void)memL;
 
     auto rsX = __builtin_amdgcn_make_buffer_rsrc(d.X, 0, (int)(2u * d.NS * G.xs_bytes), 0x00020000);
@@ -219,9 +223,19 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             *reinterpret_cast<bf16x4*>(memL + j * EC + c4) = o;
         }
         if (KIND == CHAIN_LSA) {
-            const int F = d.F, Kc = d.Kc, F1 = F + 1, CPW = (2 * Kc + 15) & ~15;
-            for (int i = tid; i < F * CPW; i += NTH) { const int f = i / CPW, ck = i - f * CPW; convwL[i] = ck < 2 * Kc ? AS.loc_conv[f * 2 * Kc + ck] : 0.f; }
-            for (int i = tid; i < A * F1; i += NTH) denseL[i] = (i % F1) < F ? AS.loc_dense[(i / F1) * F + (i % F1)] : 0.f;
+            const int F = d.F, Kc = d.Kc, F1 = F + 1, KP = (Kc + 7) & ~7, WP = 2 * KP + 8;
+            for (int i = tid; i < F * 2 * KP; i += NTH) {      // K index of the conv product: c*KP + k (8 consecutive never straddle the two channels)
+                const int f = i / (2 * KP), ck = i - f * 2 * KP, c = ck / KP, k = ck - c * KP;
+                const float x = k < Kc ? AS.loc_conv[(f * 2 + c) * Kc + k] : 0.f;
+                const __bf16 hi = (__bf16)x;
+                convwL[f * WP + ck] = hi; convwL[(F + f) * WP + ck] = (__bf16)(x - (float)hi);
+            }
+            for (int i = tid; i < A * F; i += NTH) {          // x = hi + lo with both halves in bf16: three bf16 products then carry ~16 mantissa bits
+                const float x = AS.loc_dense[i];
+                const __bf16 hi = (__bf16)x;
+                denseL[(i / F) * (F + 8) + i % F] = hi; denseL[(A + i / F) * (F + 8) + i % F] = (__bf16)(x - (float)hi);
+            }
+            (void)F1;
         }
         alen = AS.lengths ? AS.lengths[ab_] : Tin;
         if (d.max_pos > 0) alen = min(alen, d.max_pos);
@@ -566,7 +580,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 // on the matrix cores (exact fp32 fma chains).  It needs nothing of step t, so it runs HERE, in front of the poll:
                 // the workgroup would otherwise sit out the L phase's publish latency.  (The dense layer follows below, fused
                 // with the energies.)
-                const int F = d.F, Kc = d.Kc, F1 = F + 1, pad = (Kc - 1) / 2, Tw = Tin + Kc - 1, TwP = (Tw + 8 + 3) & ~3, CPW = (2 * Kc + 15) & ~15;
+                const int F = d.F, Kc = d.Kc, F1 = F + 1, pad = (Kc - 1) / 2, Tw = Tin + Kc - 1, TwP = (Tw + 8 + 3) & ~3, KP = (Kc + 7) & ~7, WP = 2 * KP + 8;
                 for (int i = tid; i < 2 * TwP; i += NTH) {
                     const int c = i / TwP, j = i % TwP - pad;
                     wpadL[i] = (j >= 0 && j < Tin) ? (c == 0 ? apL[j] : cumL[j]) : 0.f;
@@ -574,41 +588,50 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 __syncthreads();
                 const int r_ = lane & 31, h_ = lane >> 5;
                 const int njt = (Tin + 31) / 32, nft = (F + 31) / 32;
-                // loc[j][f] = sum_{c,k} Wc[f][c][k] wpad[c][j + k]: a [Tin x 2Kc] . [2Kc x F] product whose A operand is read
-                // straight out of the padded weights (Toeplitz), K index ck = c*Kc + k
+                // loc[j][f] = sum_{c,k} Wc[f][c][k] wpad[c][j + k]: a [Tin x 2KP] . [2KP x F] product whose A operand is read
+                // straight out of the padded weights (Toeplitz).  Both operands as bf16 hi + lo (lo.lo dropped: 2^-16 relative):
+                // 3 bf16 MFMAs per 16 K where the exact fp32 chain took 8 of twice the cycles; the taps' pitch (2KP + 8 halves)
+                // spreads the lanes' 16-byte reads over the banks (the fp32 taps at pitch 64 put all 32 rows on one bank)
                 for (int tile = wave; tile < njt * nft; tile += NWV) {
                     const int jt = tile / nft, ft = tile % nft;
                     const float* xr = wpadL + min(jt * 32 + r_, Tin - 1);
-                    const float* wr = convwL + min(ft * 32 + r_, F - 1) * CPW;
+                    const __bf16* wh = convwL + min(ft * 32 + r_, F - 1) * WP + 8 * h_;
                     f32x16 acc;
 #pragma unroll
                     for (int e2 = 0; e2 < 16; ++e2) acc[e2] = 0.f;
-                    // K = CPW (2 Kc zero-padded to a multiple of 16): operand pairs requested 8 at a time — a plain loop pays the
-                    // LDS round trip in front of every MFMA, and a tail mask costs a wait per element
-                    for (int k0 = 0; k0 < CPW; k0 += 16) {
-                        float av[8], bv[8];
+                    for (int k0 = 0; k0 < 2 * KP; k0 += 16) {
+                        const int ck = k0 + 8 * h_, c = ck >= KP ? 1 : 0;
+                        const float* xp = xr + c * TwP + ck - c * KP;    // (taps k >= Kc are zero; the window reads stay inside the padded row)
+                        float xv[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int ck = k0 + 2 * u + h_, c = ck >= Kc ? 1 : 0;
-                            av[u] = xr[c * TwP + ck - c * Kc]; bv[u] = wr[ck];
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
+                        for (int u = 0; u < 8; ++u) xv[u] = xp[u];
+                        bf16x8 ah, al;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
+                        for (int u = 0; u < 8; ++u) { ah[u] = (__bf16)xv[u]; al[u] = (__bf16)(xv[u] - (float)ah[u]); }
+                        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wh + k0), bl = *reinterpret_cast<const bf16x8*>(wh + F * WP + k0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
                     }
                     const int f = ft * 32 + r_;
                     if (f < F) {
 #pragma unroll
                         for (int e2 = 0; e2 < 16; ++e2) {
                             const int row = jt * 32 + (e2 & 3) + 8 * (e2 >> 2) + 4 * h_;
-                            if (row < Tin) locL[row * F1 + f] = acc[e2];
+                            if (row < Tin) {
+                                const float x = acc[e2];
+                                const __bf16 hi = (__bf16)x;
+                                locL[row * F1 + f] = x;
+                                lspL[row * (F + 8) + f] = hi; lspL[(Tin + row) * (F + 8) + f] = (__bf16)(x - (float)hi);
+                            }
                         }
                     }
                 }
                 for (int j = tid; j < Tin; j += NTH) locL[j * F1 + F] = 0.f;         // pad column (K rounded up to even)
             }
-            if (wave == 0) {                          // h_t of the item's row group, and (one request) of the L item's for step t+1
+            // (LSA: the last wave polls — it has no tile of the location conv above (4 tiles at Tin <= 128), so the poll's round trip
+            // runs underneath the other waves' MFMA chains instead of behind them)
+            if (wave == (KIND == CHAIN_LSA ? NWV - 1 : 0)) {   // h_t of the item's row group, and (one request) of the L item's for step t+1
                 const bool ok = (EARLY && hasL && more) ? poll_counters2(cntH_A, ep + 1, (unsigned)G.NUG, cntH_L, ep + 1, (unsigned)G.NUG, d.err, 3u)
                                                         : poll_counter(cntH_A, ep + 1, (unsigned)G.NUG, d.err, 3u);
                 if (!ok && lane == 0) *abortw = 1;
@@ -663,29 +686,31 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             T2_CSTAMP(8);
             if (KIND == CHAIN_LSA) {
                 // ---- LSA energies e_j = v . tanh(q + pm_j + dense(loc_j)) (attention.py:20-23, 73), dense layer and tanh fused:
-                // a wave takes a [32 channels x 32 positions] tile, pa^T = Wd . loc^T on the matrix cores (exact fp32 fma chains)
+                // a wave takes a [32 channels x 32 positions] tile, pa^T = Wd . loc^T on the matrix cores (split-bf16 operands, below)
                 // with the POSITIONS on the lanes, so each lane sums its 16 channel rows in registers; the partials of the
                 // A/32 channel tiles meet in LDS ([A/32][Tp]).  pm rows are LDS-resident with an odd pitch (conflict-free
                 // position-major reads).
-                const int F1 = d.F + 1, Ke = (d.F + 1) & ~1, njt = (Tin + 31) / 32, nat = A / 32, TinP = (Tin + 3) & ~3;
+                const int njt = (Tin + 31) / 32, nat = A / 32, TinP = (Tin + 3) & ~3;
                 const int r_ = lane & 31, h_ = lane >> 5;
                 constexpr float K2 = 2.0f * 1.44269504088896341f;
                 for (int tile = wave; tile < njt * nat; tile += NWV) {
                     const int jt = tile % njt, at = tile / njt;
                     const int j = min(jt * 32 + r_, Tin - 1);
-                    const float* dr = denseL + (at * 32 + r_) * F1 + h_;
-                    const float* lr = locL + j * F1 + h_;
+                    // pa^T tile = Wd . loc^T with both operands split into bf16 hi + lo (lo.lo dropped: 2^-16 relative): 3 bf16 MFMAs
+                    // per 16 features where the exact fp32 chain took 8 fp32 MFMAs of twice the cycles — that chain was this phase's
+                    // long pole (two waves per SIMD: 1.7 us per step on the fp32 pipe)
+                    const int DP = d.F + 8;
+                    const __bf16* dh = denseL + (at * 32 + r_) * DP + 8 * h_;
+                    const __bf16* lh = lspL + j * DP + 8 * h_;
                     f32x16 acc;
 #pragma unroll
                     for (int e2 = 0; e2 < 16; ++e2) acc[e2] = 0.f;
-                    for (int k0 = 0; k0 < Ke; k0 += 16) {                // (Ke = 32 at F = 32; operand pairs 8 at a time, as the conv above)
-                        float av[8], bv[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) { av[u] = dr[k0 + 2 * u]; bv[u] = lr[k0 + 2 * u]; }      // (F % 16 == 0: chain_plan)
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
+                    for (int k0 = 0; k0 < d.F; k0 += 16) {               // (F % 16 == 0: chain_plan)
+                        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(dh + k0), al = *reinterpret_cast<const bf16x8*>(dh + A * DP + k0);
+                        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(lh + k0), bl = *reinterpret_cast<const bf16x8*>(lh + Tin * DP + k0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
                     }
                     const float* pr = pmL + j * (A + 1) + at * 32 + 4 * h_;
                     const float* qr = qL + at * 32 + 4 * h_;
