@@ -96,7 +96,7 @@ __host__ __device__ inline Lds lds_of(const ChainDesc& d, int UT, int RT, int Ti
     m.loc = m.wpad = m.pa = m.lsp = 0;
     if (d.kind == CHAIN_LSA) {                               // per-step location features behind the reduction buffers
         const int TwP = (Tin + d.Kc - 1 + 8 + 3) & ~3;
-        m.loc = aphase; aphase += (Tin * (d.F + 1) + 3) & ~3;
+        m.loc = aphase;                                           // (the fp32 copy of the features is gone: the bf16 pair below is what is read)
         m.wpad = aphase; aphase += 2 * TwP;
         m.pa = aphase; aphase += (d.A / 32) * ((Tin + 3) & ~3);   // energy partials of the channel tiles [A/32][Tp]
         m.lsp = aphase; aphase += (Tin * (d.F + 8) + 3) & ~3;     // the features again as a bf16 hi/lo pair [2][Tin][F + 8]
@@ -152,8 +152,8 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
     float* credL = smem + M.scratch + 16 * A;                          // [NWV][EC]
     __bf16* convwL = reinterpret_cast<__bf16*>(smem + M.convw); __bf16* denseL = reinterpret_cast<__bf16*>(smem + M.dense);    // LSA: bf16 [hi|lo][F][2KP+8], [hi|lo][A][F+8]
     __bf16* lspL = reinterpret_cast<__bf16*>(smem + M.lsp);                                            // LSA: bf16 [hi|lo][Tin][F+8]
-    float* locL = smem + M.loc; float* wpadL = smem + M.wpad; float* paL = smem + M.pa;   // LSA: [Tin][F+1], [2][TwP], [A/32][Tp]
-    (void)convwL; (void)denseL; (void)locL; (void)wpadL; (void)paL; (void)lspL;
+    float* wpadL = smem + M.wpad; float* paL = smem + M.pa;   // LSA: [2][TwP], [A/32][Tp]
+    (void)convwL; (void)denseL; (void)wpadL; (void)paL; (void)lspL;
     (void)cumL; (void)qsL; (void)redL; (void)credL; (void)csL; (void)eL; (void)anL; (void)qL; (void)vL; (void)pmL; (void)memL;
 
     auto rsX = __builtin_amdgcn_make_buffer_rsrc(d.X, 0, (int)(2u * d.NS * G.xs_bytes), 0x00020000);
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             *reinterpret_cast<bf16x4*>(memL + j * EC + c4) = o;
         }
         if (KIND == CHAIN_LSA) {
-            const int F = d.F, Kc = d.Kc, F1 = F + 1, KP = (Kc + 7) & ~7, WP = 2 * KP + 8;
+            const int F = d.F, Kc = d.Kc, KP = (Kc + 7) & ~7, WP = 2 * KP + 8;
             for (int i = tid; i < F * 2 * KP; i += NTH) {      // K index of the conv product: c*KP + k (8 consecutive never straddle the two channels)
                 const int f = i / (2 * KP), ck = i - f * 2 * KP, c = ck / KP, k = ck - c * KP;
                 const float x = k < Kc ? AS.loc_conv[(f * 2 + c) * Kc + k] : 0.f;
@@ -235,7 +235,6 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 const __bf16 hi = (__bf16)x;
                 denseL[(i / F) * (F + 8) + i % F] = hi; denseL[(A + i / F) * (F + 8) + i % F] = (__bf16)(x - (float)hi);
             }
-            (void)F1;
         }
         alen = AS.lengths ? AS.lengths[ab_] : Tin;
         if (d.max_pos > 0) alen = min(alen, d.max_pos);
@@ -424,16 +423,18 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             d.dout[rb * d.WO + AS.ctx2off + c0 + c] = x;
             d.din16[rb * d.WD + AS.coff + c0 + c] = (__bf16)x;
         }
-        // LSA: the step's location features (still in locL), for the backward chain — which then repeats neither the location
-        // conv nor the tanh tile (chain_bwd.hip); the item's parts take the rows in turn
+        // LSA: the step's location features (hi + lo of the bf16 pair still in LDS: the values the energies were computed from), for
+        // the backward chain — which then repeats neither the location conv nor the tanh tile (chain_bwd.hip); the item's parts take
+        // the rows in turn
         if (KIND == CHAIN_LSA && AS.locsave) {
-            const int F = d.F, F1 = F + 1;
+            const int F = d.F, DP = F + 8;
             float* ls = AS.locsave + rb * Tin * F;
             for (int i = tid; i < Tin * (F / 4); i += NTH) {
                 const int j = i / (F / 4), f4 = (i % (F / 4)) * 4;
                 if (j % d.CS != part) continue;
-                const float* lr = locL + j * F1 + f4;
-                *reinterpret_cast<f32x4*>(ls + j * F + f4) = f32x4{lr[0], lr[1], lr[2], lr[3]};
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(lspL + j * DP + f4), lo = *reinterpret_cast<const bf16x4*>(lspL + (Tin + j) * DP + f4);
+                __builtin_nontemporal_store(f32x4{(float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]},
+                                            reinterpret_cast<f32x4*>(ls + j * F + f4));
             }
         }
 #endif
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 // on the matrix cores (exact fp32 fma chains).  It needs nothing of step t, so it runs HERE, in front of the poll:
                 // the workgroup would otherwise sit out the L phase's publish latency.  (The dense layer follows below, fused
                 // with the energies.)
-                const int F = d.F, Kc = d.Kc, F1 = F + 1, pad = (Kc - 1) / 2, Tw = Tin + Kc - 1, TwP = (Tw + 8 + 3) & ~3, KP = (Kc + 7) & ~7, WP = 2 * KP + 8;
+                const int F = d.F, Kc = d.Kc, pad = (Kc - 1) / 2, Tw = Tin + Kc - 1, TwP = (Tw + 8 + 3) & ~3, KP = (Kc + 7) & ~7, WP = 2 * KP + 8;
                 for (int i = tid; i < 2 * TwP; i += NTH) {
                     const int c = i / TwP, j = i % TwP - pad;
                     wpadL[i] = (j >= 0 && j < Tin) ? (c == 0 ? apL[j] : cumL[j]) : 0.f;
@@ -621,13 +622,11 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                             if (row < Tin) {
                                 const float x = acc[e2];
                                 const __bf16 hi = (__bf16)x;
-                                locL[row * F1 + f] = x;
                                 lspL[row * (F + 8) + f] = hi; lspL[(Tin + row) * (F + 8) + f] = (__bf16)(x - (float)hi);
                             }
                         }
                     }
                 }
-                for (int j = tid; j < Tin; j += NTH) locL[j * F1 + F] = 0.f;         // pad column (K rounded up to even)
             }
             // (LSA: the last wave polls — it has no tile of the location conv above (4 tiles at Tin <= 128), so the poll's round trip
             // runs underneath the other waves' MFMA chains instead of behind them)
@@ -729,7 +728,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                         const float x = qr[ao] + pr[ao] + acc[e2];
                         const float sg = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(K2 * x) + 1.0f);
                         sum += vr[ao] * sg;
-                        if (up) up[ao * TinP] = 1.0f - 2.0f * sg;
+                        if (up) __builtin_nontemporal_store(1.0f - 2.0f * sg, up + ao * TinP);   // (read once, by the backward pass: keep it out of the L2's way)
                     }
                     sum += __shfl_xor(sum, 32, 64);
                     if (h_ == 0 && jt * 32 + r_ < Tin) paL[at * Tp + jt * 32 + r_] = sum;
