@@ -272,13 +272,14 @@ __global__ __launch_bounds__(NTH) void chain_bwd_lstm_kernel(ChainBwdDesc d) {
 // Hops per step: G(t+1) -> A(t) -> P(t) -> G(t).
 //
 // KIND = CHAIN_LSA (LocationSensitiveAttention, attention.py:26-85; the launch path's attention_lsa_step_bwd_mfma_kernel):
-// same items, P and G shared.  The A item keeps, besides the above (processed memory from L2 instead of LDS): the conv
-// weights (zero-padded taps), dloc of the last step with `pad` halo rows on both sides, [w; cum] of two steps, the carried
-// gradient on the cumulative weights, and the d(Wd) / d(Wc) tiles as MFMA accumulators in registers.  Two quantities cross
-// the position splits: the `pad` boundary rows of dloc (stored before the publish of step t+1, read at the start of step t
-// behind the partner's arrival counter) and the softmax dot S = sum_j w_j g_j (one tagged 8-byte write-through store per
-// split and step; the slots are cleared per launch).  Everything that does not need step t's context gradient runs in
-// front of the poll for it (carried gradients, d(Wc) of step t+1, location features, pa and the tanh tile).
+// same items, P and G shared.  The A item keeps, besides the above (no processed memory: the tanh tile u = tanh(q + pm +
+// location term) and the location features of every step come from the forward chain's saved copies, layout.usave /
+// locsave): the conv weights (zero-padded taps), dloc of the last step with `pad` halo rows on both sides, [w; cum] of two
+// steps, the carried gradient on the cumulative weights, and the d(Wd) / d(Wc) tiles as MFMA accumulators in registers.
+// Two quantities cross the position splits: the `pad` boundary rows of dloc (stored before the publish of step t+1, read at
+// the start of step t; tagged 16-byte units, no counter poll) and the softmax dot S = sum_j w_j g_j (one tagged 8-byte
+// write-through store per split and step); both areas are cleared per launch.  Everything that does not need step t's
+// context gradient runs in front of the poll for it (halo rows, carried gradients, d(Wc) of step t+1, the saved tile's loads).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int ANC = 64;          // output columns of a G item (attention chain)
 constexpr int AKP = 4;           // K parts = the four gate blocks
@@ -616,17 +617,22 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
             // In front of the poll (none of it needs the context gradient of this step): halo rows of dloc(t+1) from the
             // other split, gradient carried to w_t / cum_t, d(Wc) of step t+1, location features and tanh tile of step t.
             // ------------------------------------------------------------------------------------------------------------
-            if (ep > 0) {
-                if (wave == 0 && !poll_counter(CNT(4 + as * 2 + ab_ / 32), ep, (unsigned)(min(32, B - (ab_ / 32) * 32) * 2), d.err, 11u) && lane == 0) *abortw = 1;
-                __syncthreads();
-                if (*abortw) return;
-                if (tid < pad * (F / 4)) {                                // the partner's `pad` rows next to the boundary
-                    const int row = tid / (F / 4), f4 = (tid % (F / 4)) * 4;
-                    const unsigned off = (unsigned)((((((t + 1) & 1) * d.NS + as) * B + ab_) * 2 + (1 - split)) * pad * F + row * F + f4) * 4u;
-                    const f32x4 h4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, off, 0, SC1));
-                    float* dst = dlocL + (split == 0 ? len + pad + row : row) * F1 + f4;
-                    if ((split == 0 && je < Tin) || (split == 1 && jb > 0)) { dst[0] = h4[0]; dst[1] = h4[1]; dst[2] = h4[2]; dst[3] = h4[3]; }
+            if (ep > 0 && tid < pad * (F / 4) && ((split == 0 && je < Tin) || (split == 1 && jb > 0))) {
+                // the partner's `pad` rows next to the boundary.  No poll of its arrival counter in front (a second round trip):
+                // the first word of every 16-byte unit carries the step tag of the step that wrote it (the area is cleared per
+                // launch), and the rows were stored a whole P and G phase ago — the first load finds them
+                const int row = tid / (F / 4), f4 = (tid % (F / 4)) * 4;
+                const unsigned off = (unsigned)((((((t + 1) & 1) * d.NS + as) * B + ab_) * 2 + (1 - split)) * pad * F + row * F + f4) * 4u;
+                u32x4 hw;
+                const unsigned long long tsp = __builtin_amdgcn_s_memrealtime();
+                for (;;) {
+                    hw = __builtin_amdgcn_raw_buffer_load_b128(rsK, off, 0, SC1);
+                    if ((hw.x & 1u) == step_tag(ep - 1)) break;
+                    if (__builtin_amdgcn_s_memrealtime() - tsp > SPIN_TICKS) { report_abort(d.err, 11u); *abortw = 1; break; }
                 }
+                const f32x4 h4 = __builtin_bit_cast(f32x4, hw);
+                float* dst = dlocL + (split == 0 ? len + pad + row : row) * F1 + f4;
+                dst[0] = h4[0]; dst[1] = h4[1]; dst[2] = h4[2]; dst[3] = h4[3];
             }
             // the tanh tile u = tanh(q + pm + location term) and the location features of step t, own positions: saved by the
             // forward chain (chain.hip), requested here — behind the halo rows, vector loads complete in order — and in
@@ -875,7 +881,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
             } else if (tid >= 64 && tid < 64 + pad * (F / 4)) {
                 const int i = tid - 64, row = i / (F / 4), f4 = (i % (F / 4)) * 4;
                 const float* src = dlocL + (pad + (split == 0 ? len - pad + row : row)) * F1 + f4;
-                const f32x4 h4 = {src[0], src[1], src[2], src[3]};
+                const f32x4 h4 = {tag_f32(src[0], step_tag(ep)), src[1], src[2], src[3]};
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h4), rsK,
                     (unsigned)(((((t & 1) * d.NS + as) * B + ab_) * 2 + split) * pad * F + row * F + f4) * 4u, 0, SC1);
             }
