@@ -45,3 +45,10 @@ for n, v in zip(NAMES, tot):
     if n != "-":
         print(f"  {n:44s} {v:6.2f}")
 print("  sum", round(sum(tot), 2))
+# per class of workgroup (the G item decides: context-column tiles, h-column tiles, no G item): who waits where
+cls = {"G ctx tiles": [w for w in range(256) if w < 192 and (w % 96) % 24 < 8], "G h tiles": [w for w in range(256) if w < 192 and (w % 96) % 24 >= 8],
+       "no G item": list(range(192, 256))}
+print(f"{'':46s}" + "".join(f"{k:>14s}" for k in cls))
+for i, n in enumerate(NAMES):
+    if n != "-":
+        print(f"  {n:44s}" + "".join(f"{sum(buf[w * 16 + i] for w in ws) / len(ws) / a.T / 100.0:14.2f}" for ws in cls.values()))

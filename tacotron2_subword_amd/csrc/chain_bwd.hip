@@ -360,14 +360,17 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
     if (tid == 0) *abortw = 0;
 
     // ---------------------------------------------------------------- G setup: W^T slice -> registers
-    // wave w covers k in [kp*1024 + w*128, +128) (8 k-steps); column tile c of the item: columns nt*64 + c*32 + r
-    bf16x8 W[2][8];
+    // wave w: column tile c2 = w & 1 of the item's two (columns nt*64 + c2*32 + r), K quarter kq = w >> 1 of the gate block
+    // (k in [kp*1024 + kq*256, +256): 16 k-steps).  Four waves share a column tile, so the partial tiles of BOTH column tiles
+    // meet in LDS in one round per row tile (K split over all eight waves took a round per (row tile, column tile): 4.9 us of G
+    // per step were mostly those rounds)
+    bf16x8 W[16];
     if (hasG) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                W[c][i] = *reinterpret_cast<const bf16x8*>(GS.wt16 + (long)(nt * ANC + c * 32 + r) * GS.ldwt + kp * H + (wave * 8 + i) * 16 + 8 * hk);
+        for (int i = 0; i < 16; ++i)
+            W[i] = KIND == CHAIN_LSA       // (LSA: column tile i / 8, k-steps wave*8 + i % 8 — its G phase splits K over all eight waves)
+                       ? *reinterpret_cast<const bf16x8*>(GS.wt16 + (long)(nt * ANC + (i >> 3) * 32 + r) * GS.ldwt + kp * H + (wave * 8 + (i & 7)) * 16 + 8 * hk)
+                       : *reinterpret_cast<const bf16x8*>(GS.wt16 + (long)(nt * ANC + (wave & 1) * 32 + r) * GS.ldwt + kp * H + ((wave >> 1) * 16 + i) * 16 + 8 * hk);
     }
     // ---------------------------------------------------------------- P setup
     const int pb = rt * 32 + (tid >> 4), pu = u0 + (tid & 15);
@@ -982,40 +985,77 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
             if (*abortw) return;
             T2_BSTAMP(8);
             const unsigned xb = (unsigned)((t & 1) * d.NS + gs) * xs + (unsigned)lane * 16u;
-            // (LSA keeps two MFMA accumulators of weight gradients in registers for all steps: its row tiles' fragments are
-            // requested one tile at a time)
-            constexpr bool SEQ_M = KIND == CHAIN_LSA && MT > 1;
-            u32x4 af[SEQ_M ? 1 : MT][8];
-            if constexpr (!SEQ_M) {
+            if constexpr (KIND == CHAIN_LSA) {
+                // LSA keeps two MFMA accumulators of weight gradients in registers for all steps: no room for the 16 fragments of a
+                // K quarter next to them (tried: 24-64 spilled registers, 24.7 -> 25.7 us per step).  K split over the eight waves,
+                // one reduction round per (row tile, column tile), fragments requested one row tile at a time
+                u32x4 af[8];
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        af[m][i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xb + (unsigned)(((kp * (H / 16) + wave * 8 + i) * MT + m) * 1024), 0, SC1);
-            }
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                if constexpr (SEQ_M) {
+                for (int m = 0; m < MT; ++m) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        af[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xb + (unsigned)(((kp * (H / 16) + wave * 8 + i) * MT + m) * 1024), 0, SC1);
+                        af[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xb + (unsigned)(((kp * (H / 16) + wave * 8 + i) * MT + m) * 1024), 0, SC1);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        f32x16 acc;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]), W[c * 8 + i], acc, 0, 0, 0);
+                        if (m + c > 0) __syncthreads();
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) partL[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk) * PPR + r] = acc[e];
+                        __syncthreads();
+                        if (tv < 256) {
+                            const int row = tv >> 3, c4 = (tv & 7) * 4;
+                            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int w = 0; w < NWV; ++w) sum += *reinterpret_cast<const f32x4*>(partL + (w * 32 + row) * PPR + c4);
+                            const int col = nt * ANC + c * 32 + c4;                 // column of [ctx | h]
+                            if (nt < NTC) {
+                                const int b = m * 32 + row;
+                                if (b < B)
+                                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sum), rsC,
+                                        (unsigned)(t & 1) * pbc_half + (unsigned)gs * pbc_s + (unsigned)kp * pbc_kp + (unsigned)((b * E + col) * 4), 0, SC1);
+                            } else {
+                                const int u = col - E;
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sum), rsH,
+                                    (unsigned)(t & 1) * pbh_half + (unsigned)gs * pbh_s + (unsigned)kp * pbh_kp +
+                                    (unsigned)(((((u / PU) * MT + m) * 32 + row) * PU + (u % PU)) * 4), 0, SC1);
+                            }
+                        }
+                    }
                 }
+            } else {
+                const int gkq = __builtin_amdgcn_readfirstlane(tv >> 7), gc2 = __builtin_amdgcn_readfirstlane((tv >> 6) & 1);   // (scalar: the 16 fragment offsets then sit in SGPRs)
+                // row tiles one after the other: the next tile's fragments are in flight underneath the current tile's reduction round
+                u32x4 af[16];
+                auto load_m = [&](int m) {
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    f32x16 acc;
+                    for (int i = 0; i < 16; ++i)
+                        af[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xb + (unsigned)(((kp * (H / 16) + gkq * 16 + i) * MT + m) * 1024), 0, SC1);
+                };
+                load_m(0);
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                for (int m = 0; m < MT; ++m) {
+                    f32x16 acc, acc2;                                        // two interleaved chains
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[SEQ_M ? 0 : m][i]), W[c][i], acc, 0, 0, 0);
-                    if (m + c > 0) __syncthreads();
+                    for (int e = 0; e < 16; ++e) { acc[e] = 0.f; acc2[e] = 0.f; }
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) partL[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk) * PPR + r] = acc[e];
+                    for (int i = 0; i < 16; i += 2) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]), W[i], acc, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i + 1]), W[i + 1], acc2, 0, 0, 0);
+                    }
+                    if (m + 1 < MT) load_m(m + 1);
+                    if (m > 0) __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) partL[((gkq * 2 + gc2) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk) * PPR + r] = acc[e] + acc2[e];
                     __syncthreads();
-                    if (tv < 256) {
-                        const int row = tv >> 3, c4 = (tv & 7) * 4;
+                    {   // thread (column tile c, row, 4 columns): fixed-order sum of the four K quarters
+                        const int c = tv >> 8, row = (tv & 255) >> 3, c4 = (tv & 7) * 4;
                         f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int w = 0; w < NWV; ++w) sum += *reinterpret_cast<const f32x4*>(partL + (w * 32 + row) * PPR + c4);
+                        for (int q = 0; q < 4; ++q) sum += *reinterpret_cast<const f32x4*>(partL + ((q * 2 + c) * 32 + row) * PPR + c4);
                         const int col = nt * ANC + c * 32 + c4;                 // column of [ctx | h]
                         if (nt < NTC) {
                             const int b = m * 32 + row;
