@@ -293,7 +293,7 @@ __host__ __device__ inline BwdLds bwd_lds_of(int A, int E, int Tc, int MT, int k
     m.ab = take(4); m.v = take(A); m.q = take(A); m.dctx = take(E);
     m.g = take(Tc + 8); m.de = take(Tc + 8); m.ps = take(Tc + 8); m.ap = take(Tc + 8); m.carry = take(Tc + 8);
     m.dva = take(A); m.dqo = take(A);
-    m.wq = take(PU * (A + 4));
+    m.wq = take(PU * (A + 8));                                 // Wq slice of the P item as a bf16 hi/lo pair [2][PU][A + 8]
     m.pm = take(lsa ? 0 : Tc * A); m.dpm = take(Tc * A); m.mem = take((Tc + 1) * E / 2);
     // LSA: carried gradient on the cumulative weights, conv weights, dloc of the last step with `pad` halo rows on both
     // sides (pitch F + 1, column F stays zero), [w_prev; cum_prev] of two steps (ping-pong) with the same halos
@@ -304,7 +304,7 @@ __host__ __device__ inline BwdLds bwd_lds_of(int A, int E, int Tc, int MT, int k
     // (the tile's room first holds Q = dloc . Wc^T, [Tc + 2 pad][65], of the carried-gradient step)
     const int nut = Tc * (A + 4), nq = (Tc + 2 * pad) * 65;
     m.ut = 0; m.loc = ((nut > nq ? nut : nq) + 3) & ~3; m.red = m.loc + ((Tc * (F + 1) + 3) & ~3);
-    const int sg = NWV * 32 * PPR, sp = 32 * (A + 4) + 4 * 32 * (PU + 4), sa = lsa ? m.red + 2 * NWV * A : 2 * 32 * A;
+    const int sg = NWV * 32 * PPR, sp = 32 * (A + 4) + 4 * 32 * (PU + 4) + 4 * 32 * (PU + 1), sa = lsa ? m.red + 2 * NWV * A : 2 * 32 * A;
     m.scratch = take(sg > sp ? (sg > sa ? sg : sa) : (sp > sa ? sp : sa));
     m.total = o;
     return m;
@@ -334,11 +334,12 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
     unsigned* abortw = reinterpret_cast<unsigned*>(smem + M.ab);
     float* vL = smem + M.v; float* qL = smem + M.q; float* dctxL = smem + M.dctx; float* gL = smem + M.g; float* deL = smem + M.de;
     float* psL = smem + M.ps; float* apL = smem + M.ap; float* carryL = smem + M.carry; float* dvaL = smem + M.dva; float* dqoL = smem + M.dqo;
-    float* wqL = smem + M.wq; float* pmL = smem + M.pm; float* dpmL = smem + M.dpm;
+    __bf16* wq16L = reinterpret_cast<__bf16*>(smem + M.wq); float* pmL = smem + M.pm; float* dpmL = smem + M.dpm;
     __bf16* memL = reinterpret_cast<__bf16*>(smem + M.mem);
     float* partL = smem + M.scratch;                           // G: [NWV][32][PPR]
     float* dqL = smem + M.scratch;                             // P: [32][A+4]
     float* dgL = smem + M.scratch + 32 * (A + 4);              // P: [4][32][PU+4]
+    float* dpL = dgL + 4 * 32 * (PU + 4);                      // P: [4 K quarters][32][PU+1] partial dq . Wq
     float* redL = smem + M.scratch;                            // A: [2][32][A]
 
     const int KT = K4 / 16;
@@ -387,7 +388,11 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
         pin[6] = t > 0 ? PS.c_out[((long)(t - 1) * B + b) * H + u] : 0.f;
     };
     if (hasP) {
-        for (int i = tid; i < A * PU; i += NTH) wqL[(i % PU) * (A + 4) + i / PU] = PS.wq[(long)(i / PU) * H + u0 + i % PU];      // [unit][a]
+        for (int i = tid; i < A * PU; i += NTH) {                   // [hi|lo][unit][a]: x = hi + lo, both bf16
+            const float x = PS.wq[(long)(i / PU) * H + u0 + i % PU];
+            const __bf16 hi = (__bf16)x;
+            wq16L[(i % PU) * (A + 8) + i / PU] = hi; wq16L[(PU + i % PU) * (A + 8) + i / PU] = (__bf16)(x - (float)hi);
+        }
         load_pin(d.t1 - 1, tid);
     }
     // ---------------------------------------------------------------- A setup: resident rows, zeroed accumulators
@@ -934,13 +939,37 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
             }
             __syncthreads();
             float dh = in[0];
-            {   // + dq . Wq[:, unit]   (attention.py:68: the query projection's input gradient): 16-byte LDS reads of both rows
-                const float* qr = dqL + (tid >> 4) * (A + 4);          // (broadcast across the 16 units of a row)
-                const float* wr = wqL + (tid & 15) * (A + 4);          // pitch A+4: the 16 rows start 4 banks apart
-                f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-                for (int a = 0; a < A; a += 4) acc4 += *reinterpret_cast<const f32x4*>(qr + a) * *reinterpret_cast<const f32x4*>(wr + a);
-                dh += (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+            {   // + dq . Wq[:, unit]   (attention.py:68: the query projection's input gradient): a [32 rows x A] . [A x 16 units] product
+                // on the matrix cores, K quarter per wave (waves 0..3), both operands as bf16 hi + lo (lo.lo dropped: 2^-16
+                // relative) — the thread-per-(row, unit) dot product it replaces read 64 x 16 bytes of LDS per thread and step
+                if (wave < 4) {
+                    const float* ar = dqL + r * (A + 4) + wave * 32 + 8 * hk;
+                    const __bf16* bw = wq16L + (r & 15) * (A + 8) + wave * 32 + 8 * hk;
+                    f32x16 acc;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {                     // (A = 128: 32 per wave)
+                        const f32x4 lo4 = *reinterpret_cast<const f32x4*>(ar + 16 * ks), hi4 = *reinterpret_cast<const f32x4*>(ar + 16 * ks + 4);
+                        bf16x8 ah, al;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            ah[c] = (__bf16)lo4[c]; al[c] = (__bf16)(lo4[c] - (float)ah[c]);
+                            ah[4 + c] = (__bf16)hi4[c]; al[4 + c] = (__bf16)(hi4[c] - (float)ah[4 + c]);
+                        }
+                        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(bw + 16 * ks), wl = *reinterpret_cast<const bf16x8*>(bw + PU * (A + 8) + 16 * ks);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
+                    }
+                    if (r < PU) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) dpL[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hk) * (PU + 1) + r] = acc[e];
+                    }
+                }
+                __syncthreads();
+                const float* dp = dpL + (tid >> 4) * (PU + 1) + (tid & 15);
+                dh += (dp[0] + dp[32 * (PU + 1)]) + (dp[2 * 32 * (PU + 1)] + dp[3 * 32 * (PU + 1)]);
             }
             float dcs = ep > 0 ? dc : 0.f;
             if (d.drop_p > 0.f) {
