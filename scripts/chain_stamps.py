@@ -51,3 +51,10 @@ print("mean over workgroups, us per step:")
 for n, v in zip(NAMES, tot):
     print(f"  {n:28s} {v:6.2f}")
 print("  sum", round(sum(tot), 2))
+if not a.decode:
+    # per class of workgroup: the A item's stream (B*CS workgroups per stream; the phone stream has the longer memory)
+    half = 128
+    cls = {"A item: phone stream": range(0, half), "A item: sub-word stream": range(half, 256)}
+    print(f"{'':30s}" + "".join(f"{k:>26s}" for k in cls))
+    for i, n in enumerate(NAMES):
+        print(f"  {n:28s}" + "".join(f"{sum(buf[w * 16 + i] for w in ws) / len(ws) / a.T / 100.0:26.2f}" for ws in cls.values()))

@@ -47,7 +47,7 @@ extern "C" int t2_debug_clear_chain_stamps(void) {
 #define T2_CSTAMP(i)                                                                              \
     do {                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); stamp_acc[i] += n_ - stamp_last; stamp_last = n_; } \
+        if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); t2_stamp_lds[i] += n_ - stamp_last; stamp_last = n_; } \
         __builtin_amdgcn_sched_barrier(0);                                                        \
     } while (0)
 #else
@@ -440,7 +440,11 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
 #endif
     };
 #ifdef T2_STAMPS
-    unsigned long long stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // (accumulators in LDS, 128 bytes in front of the dynamic carve: 32 more registers per thread made the stamped kernels spill and
+    //  the stamps measure the spills)
+    __shared__ __attribute__((aligned(16))) unsigned long long t2_stamp_lds[16];
+    if (threadIdx.x < 16) t2_stamp_lds[threadIdx.x] = 0;
+    __syncthreads();
     unsigned long long stamp_last = __builtin_amdgcn_s_memrealtime();
 #endif
     for (int t = d.t0; t < d.t1; ++t) {
@@ -1106,7 +1110,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
     }
 #ifdef T2_STAMPS
     if (tid == 0 && (KIND != CHAIN_LSTM) == (T2_STAMPS != 2))     // -DT2_STAMPS=1: the attention chain, =2: the decoder-LSTM chain
-        for (int i = 0; i < 16; ++i) t2_chain_stamps[wg * 16 + i] += stamp_acc[i];
+        for (int i = 0; i < 16; ++i) t2_chain_stamps[wg * 16 + i] += t2_stamp_lds[i];
 #endif
 }
 

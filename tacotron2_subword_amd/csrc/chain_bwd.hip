@@ -31,7 +31,7 @@ extern "C" int t2_debug_clear_chain_bwd_stamps(void) {
 #define T2_BSTAMP(i)                                                                              \
     do {                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); stamp_acc[i] += n_ - stamp_last; stamp_last = n_; } \
+        if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); t2_stamp_lds[i] += n_ - stamp_last; stamp_last = n_; } \
         __builtin_amdgcn_sched_barrier(0);                                                        \
     } while (0)
 #else
@@ -483,7 +483,11 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
     const float dscale = d.drop_p > 0.f ? 1.0f / (1.0f - d.drop_p) : 1.0f;
 
 #ifdef T2_STAMPS
-    unsigned long long stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // (accumulators in LDS, 128 bytes in front of the dynamic carve: 32 more registers per thread made the stamped kernels spill and
+    //  the stamps measure the spills)
+    __shared__ __attribute__((aligned(16))) unsigned long long t2_stamp_lds[16];
+    if (threadIdx.x < 16) t2_stamp_lds[threadIdx.x] = 0;
+    __syncthreads();
     unsigned long long stamp_last = __builtin_amdgcn_s_memrealtime();
 #endif
     for (int t = d.t1 - 1; t >= d.t0; --t) {
@@ -1107,7 +1111,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
     }
 #ifdef T2_STAMPS
     if (tid == 0)
-        for (int i = 0; i < 16; ++i) t2_chain_bwd_stamps[wg * 16 + i] += stamp_acc[i];
+        for (int i = 0; i < 16; ++i) t2_chain_bwd_stamps[wg * 16 + i] += t2_stamp_lds[i];
 #endif
     // ---------------------------------------------------------------- P epilogue: bias gradients (fixed-order sum over the tile's rows)
     if (PS.dbias_part) {
