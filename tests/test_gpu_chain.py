@@ -185,6 +185,34 @@ def test_backward_consumes_chain_activations(env, att):
     assert max(worst.values()) < 0.008, worst                          # observed 0.0038
 
 
+def test_lsa_backward_after_a_launch_path_forward(env):
+    """The LSA backward chain reads the tanh tile and the location features the forward CHAIN saved (layout.usave / locsave).  A
+    forward that ran one launch per step leaves them unwritten: its backward must take the launch path even with the chains on
+    (the library keeps, per workspace, whether the tile was saved) — same gradients as with the chains off, bit for bit, and no
+    persistent attention backward in the profile.  A chain forward right after, into a fresh workspace, gets the chain backward."""
+    L, ops = env
+    B, T, Tin, Tsub = 64, 12, 100, 60
+    g = torch.Generator(device="cuda").manual_seed(3)
+    dmel = torch.randn(B, T, 80, device="cuda", generator=g)
+    dgate = torch.randn(B, T, device="cuda", generator=g)
+    res, launches = {}, {}
+    for name, fwd_chain, bwd_chain in (("launch/launch", False, False), ("launch/chain-enabled", False, True), ("chain/chain", True, True)):
+        out, st, (W, P, dims, dp, mem, mems) = _run(env, LSA, B, Tin, Tsub, T, chain=fwd_chain, training=True)
+        L.set_chain(bwd_chain)
+        try:
+            L.prof_enable(8 * T + 64)
+            G, dm, dms = ops.decoder_backward(W, P, dims, dp, mem, mems, dmel, dgate, training=True, prenet_dropout=True, seed=11)
+            torch.cuda.synchronize()
+            launches[name] = L.prof_collect()["chain_a_bwd"][1]
+        finally:
+            L.set_chain(True)
+        res[name] = dict(G, d_memory=dm, d_memory_sub=dms)
+    assert launches == {"launch/launch": 0, "launch/chain-enabled": 0, "chain/chain": 1}, launches
+    for k, v in res["launch/launch"].items():
+        if v is not None:
+            assert torch.equal(v, res["launch/chain-enabled"][k]), k
+
+
 def test_reported_abort_raises_at_every_entry_point(env):
     """The sticky status word (page-locked host memory the device writes directly): an abort report is seen by the next
     entry point without any copy or synchronisation of its own, and the raise clears it."""
