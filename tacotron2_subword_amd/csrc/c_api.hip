@@ -1129,7 +1129,8 @@ int t2_decoder_forward(const t2_dims* dims_in, const t2_decoder_weights* w, cons
     saved_tiles_note(a->ws, chain_a && ca.kind == CHAIN_LSA);
     {   // status words always (0 = OK / not used); counters and the zero state of step -1 when a chain runs
         const ChainBufs bufs = chain_bufs(z, L, a->ws);
-        T2_CHECK_HIP(hipMemsetAsync(bufs.err, 0, (chain_a || chain_b) ? 256 + 2 * kChainCntBytes + bufs.xa_bytes + bufs.xb_bytes + kChainXmBytes : 256, c.s));
+        // (the query partials carry step tags: their buffer starts out cleared too)
+        T2_CHECK_HIP(hipMemsetAsync(bufs.err, 0, (chain_a || chain_b) ? 256 + 2 * kChainCntBytes + bufs.xa_bytes + bufs.xb_bytes + kChainXmBytes + bufs.q_bytes : 256, c.s));
     }
     Side* side = nullptr;
     const bool overlap = g_overlap && z.T >= 32 && !chain_a && !chain_b;

@@ -116,6 +116,11 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
     // 256-register cap, and the validation loops around their fragment and query-partial loads cost them 32-58 spilled registers
     // (tried: attention chain forward 12.7 -> 13.9 us per step); the code below is written for both and compiles away for them.
     constexpr bool TAG = !DEC && KIND == CHAIN_LSTM;
+    // Attention kinds, teacher-forced: the QUERY PARTIALS alone are tagged (bit 0 of the step count, inverted, in the first word of every
+    // 16-byte unit; one buffer, rewritten every step, cleared per launch).  The A items then do not poll the h counter at all: they
+    // load the partials and load again until the tags are this step's — one round trip instead of two behind the L items' publish,
+    // and not behind its drain.  (The L items poll the h counter themselves, inside their wait for the contexts.)
+    constexpr bool TAGQ = !DEC && KIND != CHAIN_LSTM;
     auto tag_x = [](int step) { return (unsigned)(((step >> 1) & 1) ^ 1); };
     auto tag_q = [](int step) { return (unsigned)((step & 1) ^ 1); };
     const Geo G = geo_of(d, UT, RT);
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) pre[sl][g] = pre_next[sl][g];
             T2_CSTAMP(15);
-            if (!EARLY || !hasA) {                  // (an attention item's workgroup has polled this counter in its A phase)
+            if (!EARLY || !hasA || TAGQ) {          // (decode loop: an attention item's workgroup has polled this counter in its A phase)
                 if (wave == 0 && !poll_counter(cntH_L, ep, (unsigned)G.NUG, d.err, 1u) && lane == 0) *abortw = 1;
                 __syncthreads();
                 if (*abortw) return;
@@ -564,7 +569,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                     const int row = i / (A / 4), a4 = (i % (A / 4)) * 4;
                     const f32x4 v4 = *reinterpret_cast<const f32x4*>(qsL + row * (A + 4) + a4);
                     u32x4 vw = __builtin_bit_cast(u32x4, v4);
-                    if (TAG) vw.x = (vw.x & ~1u) | tag_q(t);
+                    if (TAGQ) vw.x = (vw.x & ~1u) | tag_q((int)ep);
                     __builtin_amdgcn_raw_buffer_store_b128(vw, rsQ, qb + (unsigned)((row * A + a4) * 4), 0, SC1);
                 }
             }
@@ -634,12 +639,12 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             }
             // (LSA: the last wave polls — it has no tile of the location conv above (4 tiles at Tin <= 128), so the poll's round trip
             // runs underneath the other waves' MFMA chains instead of behind them)
-            if (wave == (KIND == CHAIN_LSA ? NWV - 1 : 0)) {   // h_t of the item's row group, and (one request) of the L item's for step t+1
+            if (!TAGQ && wave == (KIND == CHAIN_LSA ? NWV - 1 : 0)) {   // h_t of the item's row group, and (one request) of the L item's for step t+1
                 const bool ok = (EARLY && hasL && more) ? poll_counters2(cntH_A, ep + 1, (unsigned)G.NUG, cntH_L, ep + 1, (unsigned)G.NUG, d.err, 3u)
                                                         : poll_counter(cntH_A, ep + 1, (unsigned)G.NUG, d.err, 3u);
                 if (!ok && lane == 0) *abortw = 1;
             }
-            __syncthreads();
+            if (!TAGQ || KIND == CHAIN_LSA) __syncthreads();       // (LSA: the conv's bf16 pair is complete behind this barrier)
             if (*abortw) return;
             T2_CSTAMP(7);
             // ---- query = ordered sum of the unit groups' partials.  Request order: query partials (needed now), h fragments
@@ -651,15 +656,15 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 u32x4 pv[QU];
                 // (tagged hand-off: a partial that still shows last step's tag has not landed yet: load the batch again)
                 auto load_q = [&](int i0) {
-                    const unsigned long long tsp = TAG ? __builtin_amdgcn_s_memrealtime() : 0ull;
+                    const unsigned long long tsp = TAGQ ? __builtin_amdgcn_s_memrealtime() : 0ull;
                     for (;;) {
                         unsigned okw = 1u;
 #pragma unroll
                         for (int k = 0; k < QU; ++k) {
                             pv[k] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, qb + (unsigned)min(i0 + 16 * k, G.NUG - 1) * (unsigned)(32 * RT * A * 4), 0, SC1);
-                            okw &= ((pv[k].x & 1u) == tag_q(t)) ? 1u : 0u;
+                            okw &= ((pv[k].x & 1u) == tag_q((int)ep)) ? 1u : 0u;
                         }
-                        if (!TAG || __all(okw != 0u)) break;
+                        if (!TAGQ || __all(okw != 0u)) break;
                         if (__builtin_amdgcn_s_memrealtime() - tsp > SPIN_TICKS) { if ((tid & 63) == 0) { report_abort(d.err, 19u); *abortw = 1; } break; }
                     }
                 };
