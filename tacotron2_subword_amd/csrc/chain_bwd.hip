@@ -357,6 +357,27 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
     // counters: [0..1] P done per stream, [2..3] ctx tiles done per stream, [4 + s*2 + rt] A done per (stream, row tile),
     // [8 + s*16 + n] h tile n done
     auto CNT = [&](int i) { return d.cnt + (size_t)i * CNT_STRIDE; };
+    (void)CNT;
+    // Hand-offs of this kernel carry NO counters: every payload is tagged — the lowest bit of every fp32 word of the K-split
+    // partials, of the first word of every 16-byte unit elsewhere — with a bit of the step count (buffers with two parities: bit 1,
+    // inverted = step_tag; the single dq buffer: bit 0), the exchange buffers are cleared per launch, and a consumer loads its
+    // operands and loads them again until every tag is this step's.  One round trip per hop instead of two (counter poll, then
+    // the loads), no drain and no atomic on the producer's side.  Every spin is bounded (SPIN_TICKS) like the polls it replaces.
+    auto load_tagged4 = [&](auto rs, unsigned off, unsigned stride, unsigned want, float (&pv)[AKP], unsigned code) {
+        const unsigned long long tsp = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            unsigned okw = 1u;
+#pragma unroll
+            for (int z = 0; z < AKP; ++z) {
+                const unsigned wv = __builtin_amdgcn_raw_buffer_load_b32(rs, off + z * stride, 0, SC1);
+                pv[z] = __builtin_bit_cast(float, wv);
+                okw &= ((wv & 1u) == want) ? 1u : 0u;
+            }
+            if (__all(okw != 0u)) break;
+            if (__builtin_amdgcn_s_memrealtime() - tsp > SPIN_TICKS) { if ((threadIdx.x & 63) == 0) { report_abort(d.err, code); *abortw = 1; } break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    };
 
     if (tid == 0) *abortw = 0;
 
@@ -502,32 +523,34 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
             float in[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) in[i] = ain[i];
-            if (ep > 0) {
-                if (wave == 0 && !poll_counter(CNT(2 + as), ep, (unsigned)(NTC * AKP), d.err, 7u) && lane == 0) *abortw = 1;
-                __syncthreads();
-                if (*abortw) return;
-            }
             T2_BSTAMP(0);
-            // total gradient on ctx(t): direct sources + the four K-split partials of dx_ctx(t+1)
+            // total gradient on ctx(t): direct sources + the four K-split partials of dx_ctx(t+1) (tagged words: no counter poll)
             float boundary = 0.f;                                       // carry of position je, owned by the other split
             if (tid < E) {
                 float v = in[4] + in[5];
                 if (ep > 0) {
                     const unsigned off = (unsigned)((t + 1) & 1) * pbc_half + (unsigned)as * pbc_s + (unsigned)((ab_ * E + tid) * 4);
                     float pv[AKP];
-#pragma unroll
-                    for (int z = 0; z < AKP; ++z) pv[z] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsC, off + z * pbc_kp, 0, SC1));
+                    load_tagged4(rsC, off, pbc_kp, step_tag(ep - 1), pv, 7u);       // (G(t+1)'s tag on every word)
                     v += (pv[0] + pv[1]) + (pv[2] + pv[3]);
                 }
                 dctxL[tid] = v;
                 if (split == 0) AS.dctx_out[((long)t * B + ab_) * E + tid] = v;
             }
-            if (tid == 0 && ep > 0 && je < Tin)
-                boundary = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsK, (unsigned)((((t + 1) & 1) * d.NS + as) * B + ab_) * 4u, 0, SC1));
+            if (tid == 0 && ep > 0 && je < Tin) {
+                const unsigned long long tsp = __builtin_amdgcn_s_memrealtime();
+                for (;;) {
+                    const unsigned wv = __builtin_amdgcn_raw_buffer_load_b32(rsK, (unsigned)((((t + 1) & 1) * d.NS + as) * B + ab_) * 4u, 0, SC1);
+                    boundary = __builtin_bit_cast(float, wv);
+                    if ((wv & 1u) == step_tag(ep - 1)) break;
+                    if (__builtin_amdgcn_s_memrealtime() - tsp > SPIN_TICKS) { report_abort(d.err, 14u); *abortw = 1; break; }
+                }
+            }
             if (tid < A) qL[tid] = in[0];
             if (tid < len) { psL[tid] = in[1]; apL[tid] = in[2]; }
             if (tid == 0) { gL[ng] = 0.f; if (je < Tin) carryL[len] = boundary; }
             __syncthreads();
+            if (*abortw) return;
             T2_BSTAMP(1);
             // g_j = dctx . memory_j + dalign_j + carry_j: one wave per position, lanes stride the E columns 8 at a time
             for (int jl = wave; jl < ng; jl += NWV) {
@@ -557,7 +580,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                 const float co = gj * p + gn * (1.0f - p);
                 carryL[tid] = co;                                       // gradient on a_{t-1}[j], consumed at step t-1
                 if (tid == 0 && split == 1)                             // position jb of this split = je of the other one
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, co), rsK, (unsigned)(((t & 1) * d.NS + as) * B + ab_) * 4u, 0, SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tag_f32(co, step_tag(ep))), rsK, (unsigned)(((t & 1) * d.NS + as) * B + ab_) * 4u, 0, SC1);
             }
             __syncthreads();
             T2_BSTAMP(2);
@@ -609,10 +632,12 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
             __syncthreads();
             if (tid < A / 4) {
                 const f32x4 q4 = *reinterpret_cast<const f32x4*>(dqoL + tid * 4);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q4), rsQ, (unsigned)((((as * 2 + split) * B + ab_) * A + tid * 4) * 4), 0, SC1);
+                u32x4 qw = __builtin_bit_cast(u32x4, q4);
+                qw.x = (qw.x & ~1u) | ((ep & 1u) ^ 1u);                  // (the dq buffer has one parity: its tag flips every step)
+                __builtin_amdgcn_raw_buffer_store_b128(qw, rsQ, (unsigned)((((as * 2 + split) * B + ab_) * A + tid * 4) * 4), 0, SC1);
             }
             T2_BSTAMP(3);
-            publish(CNT(4 + as * 2 + ab_ / 32), (unsigned)((ab_ & 31) * 2 + split));
+            __syncthreads();                                             // (no arrival counter: the dq units carry the step's tag)
             T2_BSTAMP(4);
             if (tid < A) AS.dq_out[((long)t * B + ab_) * 2 * A + split * A + tid] = dqoL[tid];
             if (t > d.t0) load_ain(t - 1, tid);
@@ -731,19 +756,15 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
             if (tid < len) locL[tid * F1 + F] = 0.f;                      // pad column (read by lanes r >= F of the d(Wd) product)
             // ------------------------------------------------------------------------------------------------------------
             T2_BSTAMP(13);
-            if (ep > 0) {
-                if (wave == 0 && !poll_counter(CNT(2 + as), ep, (unsigned)(NTC * AKP), d.err, 7u) && lane == 0) *abortw = 1;
-                __syncthreads();
-                if (*abortw) return;
-            } else __syncthreads();
+            __syncthreads();
+            if (*abortw) return;
             T2_BSTAMP(0);
             if (tid < E) {
                 float v = in[4] + in[5];
                 if (ep > 0) {
                     const unsigned off = (unsigned)((t + 1) & 1) * pbc_half + (unsigned)as * pbc_s + (unsigned)((ab_ * E + tid) * 4);
                     float pv[AKP];
-#pragma unroll
-                    for (int z = 0; z < AKP; ++z) pv[z] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsC, off + z * pbc_kp, 0, SC1));
+                    load_tagged4(rsC, off, pbc_kp, step_tag(ep - 1), pv, 7u);       // (G(t+1)'s tag on every word)
                     v += (pv[0] + pv[1]) + (pv[2] + pv[3]);
                 }
                 dctxL[tid] = v;
@@ -889,7 +910,9 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
             // hand-offs: dq partial of this split, the `pad` rows of dloc next to the boundary
             if (tid < A / 4) {
                 const f32x4 q4 = *reinterpret_cast<const f32x4*>(dqoL + tid * 4);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q4), rsQ, (unsigned)((((as * 2 + split) * B + ab_) * A + tid * 4) * 4), 0, SC1);
+                u32x4 qw = __builtin_bit_cast(u32x4, q4);
+                qw.x = (qw.x & ~1u) | ((ep & 1u) ^ 1u);                  // (the dq buffer has one parity: its tag flips every step)
+                __builtin_amdgcn_raw_buffer_store_b128(qw, rsQ, (unsigned)((((as * 2 + split) * B + ab_) * A + tid * 4) * 4), 0, SC1);
             } else if (tid >= 64 && tid < 64 + pad * (F / 4)) {
                 const int i = tid - 64, row = i / (F / 4), f4 = (i % (F / 4)) * 4;
                 const float* src = dlocL + (pad + (split == 0 ? len - pad + row : row)) * F1 + f4;
@@ -898,7 +921,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                     (unsigned)(((((t & 1) * d.NS + as) * B + ab_) * 2 + split) * pad * F + row * F + f4) * 4u, 0, SC1);
             }
             T2_BSTAMP(3);
-            publish(CNT(4 + as * 2 + ab_ / 32), (unsigned)((ab_ & 31) * 2 + split));
+            __syncthreads();                                             // (no arrival counter: the dq units carry the step's tag)
             T2_BSTAMP(4);
             if (tid < A) AS.dq_out[((long)t * B + ab_) * 2 * A + split * A + tid] = dqoL[tid];
             if (t > d.t0) load_ain(t - 1, tid);
@@ -909,30 +932,34 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
             float in[7];
 #pragma unroll
             for (int i = 0; i < 7; ++i) in[i] = pin[i];
-            if (wave == 0) {
-                bool ok = poll_counter(CNT(4 + ps * 2 + rt), ep + 1, (unsigned)(min(32, B - rt * 32) * 2), d.err, 8u);
-                if (ok && ep > 0) ok = poll_counter(CNT(8 + ps * 16 + u0 / ANC), ep, (unsigned)AKP, d.err, 9u);
-                if (!ok && lane == 0) *abortw = 1;
-            }
-            __syncthreads();
-            if (*abortw) return;
             T2_BSTAMP(5);
             // dq rows of this row tile (two position splits summed), K-split partials of dx_h(t+1)
             {
                 u32x4 qv[2][2];
+                {
+                    const unsigned want = (ep & 1u) ^ 1u;
+                    const unsigned long long tsp = __builtin_amdgcn_s_memrealtime();
+                    for (;;) {
+                        unsigned okw = 1u;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int idx = tv + i * NTH, row = idx / (A / 4), a4 = (idx % (A / 4)) * 4;
-                    const int b = min(rt * 32 + row, B - 1);
+                        for (int i = 0; i < 2; ++i) {
+                            const int idx = tv + i * NTH, row = idx / (A / 4), a4 = (idx % (A / 4)) * 4;
+                            const int b = min(rt * 32 + row, B - 1);
 #pragma unroll
-                    for (int sp = 0; sp < 2; ++sp)
-                        qv[i][sp] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, (unsigned)((((ps * 2 + sp) * B + b) * A + a4) * 4), 0, SC1);
+                            for (int sp = 0; sp < 2; ++sp) {
+                                qv[i][sp] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, (unsigned)((((ps * 2 + sp) * B + b) * A + a4) * 4), 0, SC1);
+                                okw &= ((qv[i][sp].x & 1u) == want) ? 1u : 0u;
+                            }
+                        }
+                        if (__all(okw != 0u)) break;
+                        if (__builtin_amdgcn_s_memrealtime() - tsp > SPIN_TICKS) { if ((tv & 63) == 0) { report_abort(d.err, 8u); *abortw = 1; } break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
                 }
                 float pv[AKP] = {0.f, 0.f, 0.f, 0.f};
                 if (ep > 0) {
                     const unsigned off = (unsigned)((t + 1) & 1) * pbh_half + (unsigned)ps * pbh_s + (unsigned)((((ug * MT + rt) * 32 + (tv >> 4)) * PU + (tv & 15)) * 4);
-#pragma unroll
-                    for (int z = 0; z < AKP; ++z) pv[z] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsH, off + z * pbh_kp, 0, SC1));
+                    load_tagged4(rsH, off, pbh_kp, step_tag(ep - 1), pv, 9u);
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -942,6 +969,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                 in[0] += (pv[0] + pv[1]) + (pv[2] + pv[3]);
             }
             __syncthreads();
+            if (*abortw) return;
             float dh = in[0];
             {   // + dq . Wq[:, unit]   (attention.py:68: the query projection's input gradient): a [32 rows x A] . [A x 16 units] product
                 // on the matrix cores, K quarter per wave (waves 0..3), both operands as bf16 hi + lo (lo.lo dropped: 2^-16
@@ -996,11 +1024,13 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                 bf16x8 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { o[j] = (__bf16)lo[j]; o[4 + j] = (__bf16)hi[j]; }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsX,
+                u32x4 ow = __builtin_bit_cast(u32x4, o);
+                ow.x = (ow.x & ~1u) | step_tag(ep);
+                __builtin_amdgcn_raw_buffer_store_b128(ow, rsX,
                     (unsigned)((t & 1) * d.NS + ps) * xs + (unsigned)((((wave * H + u0) / 16) * MT + rt) * 1024 + lane * 16), 0, SC1);
             }
             T2_BSTAMP(6);
-            publish(CNT(ps), (unsigned)(wg % nPs));
+            __syncthreads();                                             // (no arrival counter: the fragments carry the step's tag)
             T2_BSTAMP(7);
             {
                 const int b = rt * 32 + (tv >> 4), u = u0 + (tv & 15);
@@ -1013,9 +1043,6 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
         }
         // ======================================================================================= G(t)
         if (hasG && t > 0) {
-            if (wave == 0 && !poll_counter(CNT(gs), ep + 1, (unsigned)nPs, d.err, 10u) && lane == 0) *abortw = 1;
-            __syncthreads();
-            if (*abortw) return;
             T2_BSTAMP(8);
             const unsigned xb = (unsigned)((t & 1) * d.NS + gs) * xs + (unsigned)lane * 16u;
             if constexpr (KIND == CHAIN_LSA) {
@@ -1025,9 +1052,20 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                 u32x4 af[8];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
+                    {
+                        const unsigned long long tsp = __builtin_amdgcn_s_memrealtime();
+                        for (;;) {                                           // (tagged fragments: load until all eight are this step's)
+                            unsigned okw = 1u;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        af[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xb + (unsigned)(((kp * (H / 16) + wave * 8 + i) * MT + m) * 1024), 0, SC1);
+                            for (int i = 0; i < 8; ++i) {
+                                af[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xb + (unsigned)(((kp * (H / 16) + wave * 8 + i) * MT + m) * 1024), 0, SC1);
+                                okw &= ((af[i].x & 1u) == step_tag(ep)) ? 1u : 0u;
+                            }
+                            if (__all(okw != 0u)) break;
+                            if (__builtin_amdgcn_s_memrealtime() - tsp > SPIN_TICKS) { if (lane == 0) { report_abort(d.err, 10u); *abortw = 1; } break; }
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                    }
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
                         f32x16 acc;
@@ -1045,6 +1083,8 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
 #pragma unroll
                             for (int w = 0; w < NWV; ++w) sum += *reinterpret_cast<const f32x4*>(partL + (w * 32 + row) * PPR + c4);
                             const int col = nt * ANC + c * 32 + c4;                 // column of [ctx | h]
+                            const unsigned tg = step_tag(ep);                       // every word carries the tag (the consumers read single words)
+                            sum[0] = tag_f32(sum[0], tg); sum[1] = tag_f32(sum[1], tg); sum[2] = tag_f32(sum[2], tg); sum[3] = tag_f32(sum[3], tg);
                             if (nt < NTC) {
                                 const int b = m * 32 + row;
                                 if (b < B)
@@ -1068,9 +1108,22 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                     for (int i = 0; i < 16; ++i)
                         af[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xb + (unsigned)(((kp * (H / 16) + gkq * 16 + i) * MT + m) * 1024), 0, SC1);
                 };
+                auto ensure_m = [&](int m) {                              // tagged fragments: load again until all sixteen are this step's
+                    const unsigned long long tsp = __builtin_amdgcn_s_memrealtime();
+                    for (;;) {
+                        unsigned okw = 1u;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) okw &= ((af[i].x & 1u) == step_tag(ep)) ? 1u : 0u;
+                        if (__all(okw != 0u)) break;
+                        if (__builtin_amdgcn_s_memrealtime() - tsp > SPIN_TICKS) { if (lane == 0) { report_abort(d.err, 10u); *abortw = 1; } break; }
+                        __builtin_amdgcn_s_sleep(2);
+                        load_m(m);
+                    }
+                };
                 load_m(0);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
+                    ensure_m(m);
                     f32x16 acc, acc2;                                        // two interleaved chains
 #pragma unroll
                     for (int e = 0; e < 16; ++e) { acc[e] = 0.f; acc2[e] = 0.f; }
@@ -1090,6 +1143,8 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) sum += *reinterpret_cast<const f32x4*>(partL + ((q * 2 + c) * 32 + row) * PPR + c4);
                         const int col = nt * ANC + c * 32 + c4;                 // column of [ctx | h]
+                        const unsigned tg = step_tag(ep);                       // every word carries the tag (the consumers read single words)
+                        sum[0] = tag_f32(sum[0], tg); sum[1] = tag_f32(sum[1], tg); sum[2] = tag_f32(sum[2], tg); sum[3] = tag_f32(sum[3], tg);
                         if (nt < NTC) {
                             const int b = m * 32 + row;
                             if (b < B)
@@ -1105,7 +1160,8 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
                 }
             }
             T2_BSTAMP(9);
-            publish(nt < NTC ? CNT(2 + gs) : CNT(8 + gs * 16 + (nt - NTC)), (unsigned)(nt < NTC ? kp * NTC + nt : kp));
+            __syncthreads();                                             // (no arrival counter: every partial word carries the step's tag)
+            if (*abortw) return;
             T2_BSTAMP(10);
         }
     }
@@ -1213,8 +1269,21 @@ int chain_bwd(const ChainBwdDesc& d, hipStream_t s) {
         T2_REQUIRE(d.PBC && d.DQX && d.CARRYX, "chain_bwd: exchange buffers missing");
         const size_t smem = (size_t)bwd_lds_of(d.A, d.E, d.lds_Tc, MT, d.kind, d.F, d.Kc).total * sizeof(float);
         const int grid = std::max(std::max(d.NS * (d.E + d.H) / ANC * AKP, d.NS * (d.H / PU) * MT), d.NS * d.B * 2);
-        if (d.kind == CHAIN_LSA) {                                   // the softmax-dot slots carry step tags: clear them
-            T2_CHECK_HIP(hipMemsetAsync(d.CARRYX, 0, chain_bwd_lsa_tagged_bytes(d), s));
+        {   // every exchange buffer carries step tags (tag 0 = not written yet): clear them
+            size_t xb, ph, pc, dq, cr;
+            chain_bwd_att_exchange_bytes(d, &xb, &ph, &pc, &dq, &cr);
+            const size_t carry = d.kind == CHAIN_LSA ? chain_bwd_lsa_tagged_bytes(d) : cr;      // (LSA: the caller's bf16 Wd^T copies follow)
+            unsigned char* c0 = reinterpret_cast<unsigned char*>(d.cnt);
+            if (d.X == c0 + kChainBwdCntBytes && d.PB == d.X + xb && d.PBC == d.PB + ph && reinterpret_cast<unsigned char*>(d.DQX) == d.PBC + pc &&
+                reinterpret_cast<unsigned char*>(d.CARRYX) == reinterpret_cast<unsigned char*>(d.DQX) + dq) {
+                T2_CHECK_HIP(hipMemsetAsync(d.X, 0, xb + ph + pc + dq + carry, s));             // (one region, as c_api.hip lays it out)
+            } else {
+                T2_CHECK_HIP(hipMemsetAsync(d.X, 0, xb, s));
+                T2_CHECK_HIP(hipMemsetAsync(d.PB, 0, ph, s));
+                T2_CHECK_HIP(hipMemsetAsync(d.PBC, 0, pc, s));
+                T2_CHECK_HIP(hipMemsetAsync(d.DQX, 0, dq, s));
+                T2_CHECK_HIP(hipMemsetAsync(d.CARRYX, 0, carry, s));
+            }
         }
         auto launch = [&](auto kernel) -> int {
             T2_TRY_RC(persistent_prepare(kernel, grid, smem));
