@@ -471,7 +471,8 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) pre[sl][g] = pre_next[sl][g];
             T2_CSTAMP(15);
-            if (!EARLY || !hasA || TAGQ) {          // (decode loop: an attention item's workgroup has polled this counter in its A phase)
+            if ((!EARLY || !hasA || TAGQ) && !TAG) {   // (decode loop: an attention item's workgroup has polled this counter in its A phase;
+                                                        //  decoder-LSTM chain: no counter at all, the h fragments are loaded until they carry this step's tag)
                 if (wave == 0 && !poll_counter(cntH_L, ep, (unsigned)G.NUG, d.err, 1u) && lane == 0) *abortw = 1;
                 __syncthreads();
                 if (*abortw) return;
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                 }
             }
             T2_CSTAMP(4);
-            if (TAG) publish_hint(cntH_L, (unsigned)ug); else publish(cntH_L, (unsigned)ug);
+            if (TAG) { __syncthreads(); if (*abortw) return; } else publish(cntH_L, (unsigned)ug);   // (TAG: no arrival counter, the fragments carry the step's tag)
             T2_CSTAMP(5);
             // saved activations: issued here, in the slack before the next poll is answered (issuing scattered stores costs
             // the wave hundreds of cycles; behind the next phase's loads they sat on the critical path: measured +1.2 us/step)

@@ -70,11 +70,7 @@ __global__ __launch_bounds__(NTH) void chain_bwd_lstm_kernel(ChainBwdDesc d) {
     auto rsX = __builtin_amdgcn_make_buffer_rsrc(d.X, 0, (int)(2u * KT * MT * 1024u), 0x00020000);
     auto rsP = __builtin_amdgcn_make_buffer_rsrc(d.PB, 0, (int)d.pb_bytes, 0x00020000);
     const unsigned pb_half = d.pb_bytes / 2;                  // one parity of the partial buffer
-    unsigned* cntP = d.cnt + (size_t)(kp & 1) * CNT_STRIDE;   // G waits for the P items of its unit half
-    unsigned* cntP_mine = d.cnt + (size_t)(u0 >= H / 2 ? 1 : 0) * CNT_STRIDE;
-    unsigned* cntG_wait = d.cnt + (size_t)(2 + u0 / GNC) * CNT_STRIDE;    // P waits for the 8 K parts of its column tile
-    unsigned* cntG_mine = d.cnt + (size_t)(2 + nt) * CNT_STRIDE;
-    const unsigned nP_half = (unsigned)(H / 2 / PU * MT);
+    // (no arrival counters: dg fragments and K-split partial words carry step tags, consumers load until the tags are this step's)
 
     if (tid == 0) *abortw = 0;
 
@@ -117,11 +113,8 @@ __global__ __launch_bounds__(NTH) void chain_bwd_lstm_kernel(ChainBwdDesc d) {
             for (int i = 0; i < 7; ++i) in[i] = pin[i];
             float dh = in[0];
             if (ep > 0 || resumed) {
-                if (ep > 0) {                                         // (a resumed launch finds step t1's partials complete)
-                    if (wave == 0 && !poll_counter(cntG_wait, ep, (unsigned)GKP, d.err, 5u) && lane == 0) *abortw = 1;
-                    __syncthreads();
-                    if (*abortw) return;
-                }
+                // (no counter poll: the partial words carry G(t+1)'s tag and are loaded until they show it; a resumed launch
+                //  finds step t1's partials complete)
                 // dx(t+1)[row, unit] = fixed-order sum of the 8 K-split partials (written by G(t+1) into parity (t+1)&1)
                 const unsigned off = (unsigned)(((t + 1) & 1)) * pb_half + (unsigned)((((ug * MT + rt) * 32 + (tv >> 4)) * PU + (tv & 15)) * 4);
                 const unsigned kstride = (unsigned)((H / PU) * MT * 32 * PU * 4);
@@ -175,7 +168,8 @@ __global__ __launch_bounds__(NTH) void chain_bwd_lstm_kernel(ChainBwdDesc d) {
                 __builtin_amdgcn_raw_buffer_store_b128(ow, rsX,
                     (unsigned)(t & 1) * (unsigned)(KT * MT * 1024) + (unsigned)((((wave * H + u0) / 16) * MT + rt) * 1024 + lane * 16), 0, SC1);
             }
-            publish_hint(cntP_mine, (unsigned)(((u0 % (H / 2)) / PU) * MT + rt));
+            __syncthreads();                                          // (dgL is read; G's partial tiles alias it)
+            if (*abortw) return;
             {   // fp32 dg(t) rows for the weight-gradient GEMMs, then next step's operands (cold HBM rows) behind them
                 const int b = rt * 32 + (tv >> 4), u = u0 + (tv & 15);
                 if (b < B) {
@@ -187,9 +181,6 @@ __global__ __launch_bounds__(NTH) void chain_bwd_lstm_kernel(ChainBwdDesc d) {
         }
         // ======================================================================================= G(t)
         if (hasG && t > 0) {                                          // (dx(0) feeds nothing)
-            if (wave == 0 && !poll_counter(cntP, ep + 1, nP_half, d.err, 6u) && lane == 0) *abortw = 1;
-            __syncthreads();
-            if (*abortw) return;
             f32x16 acc[MT];
             const unsigned xb = (unsigned)(t & 1) * (unsigned)(KT * MT * 1024) + (unsigned)lane * 16u;
             u32x4 af[MT][4];
@@ -234,7 +225,8 @@ __global__ __launch_bounds__(NTH) void chain_bwd_lstm_kernel(ChainBwdDesc d) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sum), rsP,
                     (unsigned)(t & 1) * pb_half + (unsigned)((((kp * (H / PU) + ugo) * MT + m) * 32 + row) * PU + (c4 % PU)) * 4u, 0, SC1);
             }
-            publish_hint(cntG_mine, (unsigned)kp);
+            __syncthreads();
+            if (*abortw) return;
         }
     }
     if (hasP && d.t0 > 0 && pb < B) S.dc_state[(long)pb * H + pu] = dc;       // for the launch that continues at t0 - 1
