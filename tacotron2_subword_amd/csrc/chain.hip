@@ -111,11 +111,13 @@ template <int UT, int RT, int KH, int KC, int KIND, int KPN = 0>
 __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
     constexpr int NTILE = UT * RT, NSLOT = (NTILE + 1) / 2, HSP = UT * 8 + 4;
     constexpr bool DEC = KPN > 0;                       // decode loop: prenet segment in the LSTM product + decoder LSTM, projections, prenets in the launch
-    // Decoder-LSTM chain: tagged, drain-free hand-offs (chain_common.h): fragments of step t carry bit 1 of t (inverted) in the
-    // lowest bit of their first word; the arrival adds are hints.  The attention kinds keep the drained protocol: they sit at the
-    // 256-register cap, and the validation loops around their fragment and query-partial loads cost them 32-58 spilled registers
-    // (tried: attention chain forward 12.7 -> 13.9 us per step); the code below is written for both and compiles away for them.
-    constexpr bool TAG = !DEC && KIND == CHAIN_LSTM;
+    // Teacher-forced chains (every kind): NO arrival counters.  Fragments of step t carry bit 1 of t (inverted) in the lowest bit of
+    // their first word, the exchange buffers are cleared per launch, and a consumer loads its fragments and loads them again until
+    // they show the step's tag (bounded): one round trip per hop instead of a counter poll followed by the loads, no drain and no
+    // atomic on the producer's side.  (Round 3, first try: tags checked BEHIND the polls — the attention kinds, at the 256-register
+    // cap, spilled 32-58 registers and got slower; without the polls they spill 3-8 and gain 0.6 us per step.)  The decode loop
+    // keeps the drained protocol with counters (its 8-byte dec_h pieces and five hops are not converted).
+    constexpr bool TAG = !DEC;
     // Attention kinds, teacher-forced: the QUERY PARTIALS alone are tagged (bit 0 of the step count, inverted, in the first word of every
     // 16-byte unit; one buffer, rewritten every step, cleared per launch).  The A items then do not poll the h counter at all: they
     // load the partials and load again until the tags are this step's — one round trip instead of two behind the L items' publish,
@@ -280,13 +282,14 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
         constexpr int NK = decltype(nk)::value;
         u32x4 af[NK > 0 ? NK : 1];
         const bool chk = TAG && step >= d.t0;               // (fragments of step t0 - 1: a finished launch or the zero state)
+        const bool rowpad = min(rg * RT + rt, G.MT - 1) * 32 + (int)(threadIdx.x & 31) >= B;
         const unsigned long long tsp = chk ? __builtin_amdgcn_s_memrealtime() : 0ull;
         for (;;) {
             unsigned okw = 1u;
 #pragma unroll
             for (int i = 0; i < NK; ++i) {
                 af[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, frag_offset(step, rt, kt0 + i), 0, SC1);
-                okw &= ((af[i].x & 1u) == tag_x(step)) ? 1u : 0u;       // (h fragments: every row of a tile is written, padding rows as zeros)
+                okw &= ((af[i].x & 1u) == tag_x(step) || rowpad) ? 1u : 0u;   // (ctx units of padding rows are never written; h fragments: every row is)
             }
             if (!chk || __all(okw != 0u)) break;
             if (__builtin_amdgcn_s_memrealtime() - tsp > SPIN_TICKS) { if ((threadIdx.x & 63) == 0) { report_abort(d.err, 17u); *abortw = 1; } break; }
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
             }
             T2_CSTAMP(0);
             if (EARLY) issue_h(t - 1);
-            if (KC > 0) {
+            if (KC > 0 && !TAG) {
                 if (wave == 0) {
                     bool ok = poll_counter(cntC_L, ep, nA_per_step, d.err, 2u);
                     if (ok && DEC) ok = poll_counter(d.cnt + (size_t)(10 + ls) * CNT_STRIDE, ep, (unsigned)(d.P / 16), d.err, 11u);   // prenet output of this step
@@ -906,7 +909,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                     xout + (unsigned)as * G.xs_bytes + (unsigned)(((kt * G.MT + ab_ / 32) * 64 + (pc & 1) * 32 + (ab_ & 31)) * 16), 0, SC1);
             }
             T2_CSTAMP(11);
-            if (TAG) publish_hint(cntC_A, (unsigned)(arow * d.CS + part)); else publish(cntC_A, (unsigned)(arow * d.CS + part));
+            if (TAG) { __syncthreads(); if (*abortw) return; } else publish(cntC_A, (unsigned)(arow * d.CS + part));
             T2_CSTAMP(12);
             store_A_saved(t, tid);
         }
