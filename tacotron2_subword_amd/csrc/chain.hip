@@ -11,11 +11,12 @@
 //   h_t   (bf16, MFMA-fragment order)        units -> every workgroup of the same stream and row group
 //   q_t   (fp32 partial query projections)   units -> the item's attention workgroups
 //   ctx_t (bf16, MFMA-fragment order)        items -> every LSTM workgroup of the same stream and row group
-// exchanged through L2-bypassing write-through stores (sc1), one arrival counter per (stream, row group, kind) and
-// sc1 loads on the consumer side (MI355X_MICROARCH.md "Valid forms": every payload store sc1 and drained by every
-// storing wave before the workgroup barrier, one lane signals with an agent-scope atomic, one wave polls with
-// relaxed agent loads, the other waves load behind the workgroup barrier, every payload load sc1).
-// scripts/persist_probe.hip measures this exact traffic pattern: ~3.4 us per all-to-all hop, two hops per step.
+// exchanged through L2-bypassing write-through stores (sc1) and sc1 loads.  Decode loop: one arrival counter per (stream,
+// row group, kind) — MI355X_MICROARCH.md "Valid forms": every payload store drained by every storing wave before the
+// workgroup barrier, one lane signals with an agent-scope atomic, one wave polls with relaxed agent loads, the other waves
+// load behind the workgroup barrier (scripts/persist_probe.hip measures this pattern).  Teacher-forced chains (round 3): NO
+// counters — every 16-byte unit carries a step tag in the lowest bit of its first word, the buffers are cleared per launch,
+// a consumer loads until its units show the step's tag (see TAG / TAGQ in the kernel): one round trip per hop, two hops per step.
 //
 // Work items (one workgroup of 512 threads per CU, grid = 256):
 //   L item (s, ug, rg): stream s, unit group ug (8*UT hidden units = 32*UT gate columns), row group rg (32*RT batch rows).

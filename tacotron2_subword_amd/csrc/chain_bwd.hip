@@ -13,8 +13,9 @@
 //       in fixed order, adds the direct gradient, dropout masks, gate derivatives; keeps dL/dc in a register across
 //       steps; publishes dg(t) as four bf16 MFMA fragments (one per gate) and stores the fp32 dg(t) rows the
 //       weight-gradient GEMMs read afterwards.
-// Hand-offs: chain_common.h (one arrival counter per consumer group: the two unit halves for G, the 32 column tiles for
-// P).  Two all-to-all hops per step instead of two launches; numerics = the launch path (lstm.hip) up to summation order.
+// Hand-offs: no arrival counters (round 3) — dg fragments and K-split partial words carry step tags (chain_common.h: step_tag,
+// tag_f32), the exchange buffers are cleared per launch, consumers load until the tags are this step's.  Two all-to-all hops
+// per step instead of two launches; numerics = the launch path (lstm.hip) up to summation order.
 #include <algorithm>
 
 #include "chain_common.h"
@@ -346,10 +347,6 @@ __global__ __launch_bounds__(NTH) void chain_bwd_att_kernel(ChainBwdDesc d) {
     const unsigned pbh_half = d.pb_bytes / 2, pbc_half = d.pbc_bytes / 2;
     const unsigned pbh_kp = (unsigned)((H / PU) * MT * 32 * PU * 4), pbh_s = pbh_kp * AKP;     // bytes per K part / per stream
     const unsigned pbc_kp = (unsigned)(B * E * 4), pbc_s = pbc_kp * AKP;
-    // counters: [0..1] P done per stream, [2..3] ctx tiles done per stream, [4 + s*2 + rt] A done per (stream, row tile),
-    // [8 + s*16 + n] h tile n done
-    auto CNT = [&](int i) { return d.cnt + (size_t)i * CNT_STRIDE; };
-    (void)CNT;
     // Hand-offs of this kernel carry NO counters: every payload is tagged — the lowest bit of every fp32 word of the K-split
     // partials, of the first word of every 16-byte unit elsewhere — with a bit of the step count (buffers with two parities: bit 1,
     // inverted = step_tag; the single dq buffer: bit 0), the exchange buffers are cleared per launch, and a consumer loads its

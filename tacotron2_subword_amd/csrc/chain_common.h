@@ -84,7 +84,9 @@ __device__ __forceinline__ void publish(unsigned* cnt, unsigned pidx) {
     if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt + (pidx & (NSH - 1)) * CNT_LINE, 1u, T2_RLX_AGENT);
 }
 
-// ---- tagged, drain-free hand-off (round 3, chain_bwd_lstm_kernel) ---------------------------------------------------------
+// ---- tagged hand-offs (round 3) ------------------------------------------------------------------------------------------
+// First form (kept for reference: publish_hint): counters as hints + validated payloads.  Final form, every teacher-forced chain:
+// NO counter at all — the consumers load their operands until the tags below are this step's (see chain.hip / chain_bwd.hip).
 // The producer's s_waitcnt vmcnt(0) in front of its arrival add costs the consumers the store round trip of the slowest
 // producer.  Here the add goes out right behind the stores (a HINT), and the payload validates itself: bit 0 of every stored
 // 32-bit word (fp32 payloads) or of the first word of every 16-byte unit (bf16 fragments) is a tag that flips each time a
