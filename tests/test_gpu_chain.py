@@ -185,6 +185,32 @@ def test_backward_consumes_chain_activations(env, att):
     assert max(worst.values()) < 0.008, worst                          # observed 0.0038
 
 
+@pytest.mark.parametrize("att", [SMA, LSA])
+def test_chains_are_bit_reproducible(env, att):
+    """The hand-offs of the teacher-forced chains carry no counters: a consumer accepts a unit when its step tag fits.  A stale or
+    torn unit that slipped through would change some output bit.  Same inputs, same seeds, forward + backward five times over
+    (dropout and noise on; 64 x 100 / 60 positions, 40 steps — the tags of a parity buffer repeat every four steps): every output
+    and every gradient bit-identical, and no status word set."""
+    L, ops = env
+    B, T, Tin, Tsub = 64, 40, 100, 60
+    g = torch.Generator(device="cuda").manual_seed(3)
+    dmel = torch.randn(B, T, 80, device="cuda", generator=g)
+    dgate = torch.randn(B, T, device="cuda", generator=g)
+    ref = None
+    for rep in range(5):
+        out, st, (W, P, dims, dp, mem, mems) = _run(env, att, B, Tin, Tsub, T, chain=True, training=True)
+        assert not any(st), st
+        G, dm, dms = ops.decoder_backward(W, P, dims, dp, mem, mems, dmel, dgate, training=True, prenet_dropout=True, seed=11)
+        torch.cuda.synchronize()
+        assert not any(dp.chain_status()), dp.chain_status()
+        cur = dict(out, **{"grad_" + k: v for k, v in G.items()}, d_memory=dm, d_memory_sub=dms)
+        if ref is None:
+            ref = {k: v.clone() for k, v in cur.items() if v is not None}
+        else:
+            for k, v in ref.items():
+                assert torch.equal(v, cur[k]), (rep, k, float((v - cur[k]).abs().max()))
+
+
 def test_lsa_backward_after_a_launch_path_forward(env):
     """The LSA backward chain reads the tanh tile and the location features the forward CHAIN saved (layout.usave / locsave).  A
     forward that ran one launch per step leaves them unwritten: its backward must take the launch path even with the chains on
