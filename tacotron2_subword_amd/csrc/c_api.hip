@@ -1502,7 +1502,7 @@ int t2_decoder_infer(const t2_dims* dims_in, const t2_decoder_weights* w, const 
     if (chain && a->poll_every <= 0) poll = 32;                      // one persistent launch per polling interval: 32 steps amortise its start-up
     if (chain) {                                                     // status, counters, zero state of step -1 (h, ctx, dec_h, go-frame prenet = 0)
         const ChainBufs bufs = chain_bufs(z, L, a->ws);
-        T2_CHECK_HIP(hipMemsetAsync(bufs.err, 0, 256 + 2 * kChainCntBytes + bufs.xa_bytes + bufs.xb_bytes + kChainXmBytes, c.s));
+        T2_CHECK_HIP(hipMemsetAsync(bufs.err, 0, 256 + 2 * kChainCntBytes + bufs.xa_bytes + bufs.xb_bytes + kChainXmBytes + bufs.q_bytes, c.s));   // (+ the tagged query partials)
     } else {
         const ChainBufs bufs = chain_bufs(z, L, a->ws);
         T2_CHECK_HIP(hipMemsetAsync(bufs.err, 0, 256, c.s));

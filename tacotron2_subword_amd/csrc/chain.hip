@@ -123,7 +123,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
     // 16-byte unit; one buffer, rewritten every step, cleared per launch).  The A items then do not poll the h counter at all: they
     // load the partials and load again until the tags are this step's — one round trip instead of two behind the L items' publish,
     // and not behind its drain.  (The L items poll the h counter themselves, inside their wait for the contexts.)
-    constexpr bool TAGQ = !DEC && KIND != CHAIN_LSTM;
+    constexpr bool TAGQ = KIND != CHAIN_LSTM;             // (the decode loop too: its A items have just finished their L items — a short wait)
     auto tag_x = [](int step) { return (unsigned)(((step >> 1) & 1) ^ 1); };
     auto tag_q = [](int step) { return (unsigned)((step & 1) ^ 1); };
     const Geo G = geo_of(d, UT, RT);
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
                     const int row = i / (A / 4), a4 = (i % (A / 4)) * 4;
                     const f32x4 v4 = *reinterpret_cast<const f32x4*>(qsL + row * (A + 4) + a4);
                     u32x4 vw = __builtin_bit_cast(u32x4, v4);
-                    if (TAGQ) vw.x = (vw.x & ~1u) | tag_q((int)ep);
+                    if (TAGQ) vw.x = (vw.x & ~1u) | tag_q(t);          // (absolute step: the decode loop's launches continue each other)
                     __builtin_amdgcn_raw_buffer_store_b128(vw, rsQ, qb + (unsigned)((row * A + a4) * 4), 0, SC1);
                 }
             }
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(NTH) void chain_fwd_kernel(ChainDesc d) {
 #pragma unroll
                         for (int k = 0; k < QU; ++k) {
                             pv[k] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, qb + (unsigned)min(i0 + 16 * k, G.NUG - 1) * (unsigned)(32 * RT * A * 4), 0, SC1);
-                            okw &= ((pv[k].x & 1u) == tag_q((int)ep)) ? 1u : 0u;
+                            okw &= ((pv[k].x & 1u) == tag_q(t)) ? 1u : 0u;
                         }
                         if (!TAGQ || __all(okw != 0u)) break;
                         if (__builtin_amdgcn_s_memrealtime() - tsp > SPIN_TICKS) { if ((tid & 63) == 0) { report_abort(d.err, 19u); *abortw = 1; } break; }
