@@ -44,7 +44,8 @@ enum {
 const char* t2_last_error(void);
 /* ABI version: bumped whenever a struct below grows or an argument changes meaning.  2 (round 3): t2_dims carries
  * score_mask_value[_sub], the layouts carry chain / chain_floats, norm_out of t2_adam_* is 4 floats.  A caller compiled
- * against another version passes structs of another size: check t2_version() == T2_ABI_VERSION before anything else. */
+ * against another version passes structs of another size: check t2_version() == T2_ABI_VERSION before anything else.
+ * 3: t2_decoder_layout carries usave / usaves / locsave / locsaves (LSA: tanh tile and location features of every step). */
 #define T2_ABI_VERSION 3
 int t2_version(void);
 /* Sticky status of the persistent kernels of the current device (the reference's nearest analogue: train.py:335-340,
@@ -74,7 +75,8 @@ int t2_set_overlap(int on);
 /* Persistent chain kernels (csrc/chain.hip), bf16 mode, default dims, B <= 128, SMA: 1 (default; env T2_CHAIN=0 turns it
  * off) runs ALL steps of the attention chain (both attention LSTMs + attention; model.py:322-369) and of the decoder-LSTM
  * chain (model.py:371-373) of a teacher-forced pass in one launch each, with the recurrent weights resident in registers
- * and h / ctx / query partials exchanged between workgroups through write-through stores and arrival counters.  They need
+ * and h / ctx / query partials exchanged between workgroups through write-through stores whose 16-byte units carry a step
+ * tag the consumers validate (teacher-forced passes; the decode loop and the encoder chains use arrival counters).  They need
  * the whole device (256 co-resident workgroups): ONE process per GPU, as the reference runs (distributed.py:181-200).
  * A chain that could not make progress for 1 s gives up and leaves a non-zero status word in the workspace
  * (t2_decoder_layout.chain); 0: one launch per step and kernel, as in round 1. */
